@@ -1,0 +1,209 @@
+"""ctypes binding of libgenrec_hip.so (declared in include/genrec_hip.h).
+
+There is no fallback: if the shared library is missing or a call fails, an
+exception is raised.  Build it with ``make -C genrec_amd/csrc`` (or
+``python -c "import __graft_entry__ as g; g.build()"`` from the repo root).
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+LIB_NAME = "libgenrec_hip.so"
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
+
+GRX_OK = 0
+GRX_F32, GRX_BF16, GRX_F16 = 0, 1, 2
+GRX_MODE_COUNT, GRX_MODE_FIXED_HINT = 0, 1
+GRX_ROWERR_NONE, GRX_ROWERR_EMPTY, GRX_ROWERR_NOMATCH, GRX_ROWERR_OVERFLOW = 0, 1, 2, 3
+GRX_MAX_PREFIX = 16
+
+# Every symbol include/genrec_hip.h declares.
+EXPORTED_SYMBOLS = (
+    "grx_abi_version",
+    "grx_last_error",
+    "grx_trie_create",
+    "grx_trie_destroy",
+    "grx_trie_max_fanout",
+    "grx_trie_max_token",
+    "grx_state_create",
+    "grx_state_destroy",
+    "grx_state_set_count",
+    "grx_state_clear_error",
+    "grx_state_read",
+    "grx_workspace_bytes",
+    "grx_constrained_logsoftmax",
+    "grx_constrained_candidates",
+    "grx_beam_step",
+    "grx_sid_rewards",
+    "grx_hit_ranks",
+    "grx_group_advantage",
+    "grx_group_normalize_tokenwise",
+)
+
+
+class GrxRows(C.Structure):
+    _fields_ = [
+        ("input_ids", C.c_void_p),
+        ("ids_stride", C.c_int64),
+        ("R", C.c_int32),
+        ("T", C.c_int32),
+        ("scores", C.c_void_p),
+        ("scores_stride", C.c_int64),
+        ("V", C.c_int32),
+        ("dtype", C.c_int32),
+    ]
+
+
+class GrxConstraint(C.Structure):
+    _fields_ = [
+        ("mode", C.c_int32),
+        ("prefix_index", C.c_int32),
+        ("n_prefix", C.c_int32),
+        ("eos_token_id", C.c_int32),
+        ("prefix_ids", C.c_int64 * GRX_MAX_PREFIX),
+    ]
+
+
+class GrxBeamStepArgs(C.Structure):
+    _fields_ = [
+        ("B", C.c_int32),
+        ("K", C.c_int32),
+        ("V", C.c_int32),
+        ("n_keep", C.c_int32),
+        ("cmax", C.c_int32),
+        ("cur_len", C.c_int32),
+        ("prompt_len", C.c_int32),
+        ("max_length", C.c_int32),
+        ("copy_from", C.c_int32),
+        ("eos_token_id", C.c_int32),
+        ("early_stopping", C.c_int32),
+        ("length_penalty", C.c_float),
+        ("cand_count", C.c_void_p),
+        ("cand_tok", C.c_void_p),
+        ("cand_logp", C.c_void_p),
+        ("run_seq_in", C.c_void_p),
+        ("run_seq_out", C.c_void_p),
+        ("run_score_in", C.c_void_p),
+        ("run_score_out", C.c_void_p),
+        ("run_bidx_in", C.c_void_p),
+        ("run_bidx_out", C.c_void_p),
+        ("fin_seq_in", C.c_void_p),
+        ("fin_seq_out", C.c_void_p),
+        ("fin_score_in", C.c_void_p),
+        ("fin_score_out", C.c_void_p),
+        ("fin_bidx_in", C.c_void_p),
+        ("fin_bidx_out", C.c_void_p),
+        ("fin_done_in", C.c_void_p),
+        ("fin_done_out", C.c_void_p),
+        ("unsat", C.c_void_p),
+        ("topk_score", C.c_void_p),
+        ("topk_parent", C.c_void_p),
+        ("topk_token", C.c_void_p),
+        ("topk_hit", C.c_void_p),
+        ("next_parent", C.c_void_p),
+    ]
+
+
+_lock = threading.Lock()
+_lib = None
+
+
+class GenrecHipError(RuntimeError):
+    """A libgenrec_hip.so call returned a failure status."""
+
+
+def _declare(lib: C.CDLL) -> None:
+    vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+    lib.grx_abi_version.restype = C.c_int
+    lib.grx_abi_version.argtypes = []
+    lib.grx_last_error.restype = C.c_char_p
+    lib.grx_last_error.argtypes = []
+    lib.grx_trie_create.restype = C.c_int
+    lib.grx_trie_create.argtypes = [vp, vp, i32, i32, C.POINTER(vp)]
+    lib.grx_trie_destroy.restype = C.c_int
+    lib.grx_trie_destroy.argtypes = [vp]
+    lib.grx_trie_max_fanout.restype = i32
+    lib.grx_trie_max_fanout.argtypes = [vp]
+    lib.grx_trie_max_token.restype = i32
+    lib.grx_trie_max_token.argtypes = [vp]
+    lib.grx_state_create.restype = C.c_int
+    lib.grx_state_create.argtypes = [C.POINTER(vp)]
+    lib.grx_state_destroy.restype = C.c_int
+    lib.grx_state_destroy.argtypes = [vp]
+    lib.grx_state_set_count.restype = C.c_int
+    lib.grx_state_set_count.argtypes = [vp, i32, vp]
+    lib.grx_state_clear_error.restype = C.c_int
+    lib.grx_state_clear_error.argtypes = [vp, vp]
+    lib.grx_state_read.restype = C.c_int
+    lib.grx_state_read.argtypes = [vp, C.POINTER(i32 * 4), vp]
+    lib.grx_workspace_bytes.restype = C.c_size_t
+    lib.grx_workspace_bytes.argtypes = [i32]
+    lib.grx_constrained_logsoftmax.restype = C.c_int
+    lib.grx_constrained_logsoftmax.argtypes = [
+        vp, vp, C.POINTER(GrxRows), C.POINTER(GrxConstraint), vp, i64, i32, vp, C.c_size_t, vp,
+    ]
+    lib.grx_constrained_candidates.restype = C.c_int
+    lib.grx_constrained_candidates.argtypes = [
+        vp, vp, C.POINTER(GrxRows), C.POINTER(GrxConstraint), vp, vp, vp, i32, vp, C.c_size_t, vp,
+    ]
+    lib.grx_beam_step.restype = C.c_int
+    lib.grx_beam_step.argtypes = [C.POINTER(GrxBeamStepArgs), vp]
+    lib.grx_sid_rewards.restype = C.c_int
+    lib.grx_sid_rewards.argtypes = [vp, vp, i32, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]
+    lib.grx_hit_ranks.restype = C.c_int
+    lib.grx_hit_ranks.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp]
+    lib.grx_group_advantage.restype = C.c_int
+    lib.grx_group_advantage.argtypes = [vp, vp, i32, i32, i32, i32, f32, vp, vp, vp, vp, vp]
+    lib.grx_group_normalize_tokenwise.restype = C.c_int
+    lib.grx_group_normalize_tokenwise.argtypes = [vp, vp, i32, i32, i32, f32, vp, vp]
+
+
+def lib() -> C.CDLL:
+    """The loaded library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise GenrecHipError(
+                        f"{LIB_PATH} not found: the HIP extension is not built "
+                        "(run `make -C genrec_amd/csrc`); genrec_amd has no CPU fallback"
+                    )
+                handle = C.CDLL(LIB_PATH)
+                _declare(handle)
+                _lib = handle
+    return _lib
+
+
+def check(status: int) -> None:
+    if status != GRX_OK:
+        msg = lib().grx_last_error()
+        raise GenrecHipError(f"libgenrec_hip status {status}: {msg.decode() if msg else '?'}")
+
+
+def torch_dtype_code(dtype) -> int:
+    import torch
+
+    if dtype == torch.float32:
+        return GRX_F32
+    if dtype == torch.bfloat16:
+        return GRX_BF16
+    if dtype == torch.float16:
+        return GRX_F16
+    raise TypeError(f"unsupported logits dtype {dtype}; expected float32, bfloat16 or float16")
+
+
+def require_cuda(t, what: str) -> None:
+    if not t.is_cuda:
+        raise GenrecHipError(
+            f"{what} must live on the GPU (got device {t.device}); genrec_amd runs on MI355X only and has no CPU path"
+        )
+
+
+def current_stream_ptr(device) -> int:
+    import torch
+
+    return int(torch.cuda.current_stream(device).cuda_stream)

@@ -1,0 +1,287 @@
+// One beam-search iteration over compact candidates.  One workgroup per prompt
+// group: top-n_keep selection over the K * (allowed tokens) accumulated scores,
+// stopping criteria, running top-K, finished-beam merge, sequence / parent
+// gather and the early-stop heuristic.  Candidate counts are tiny next to the
+// vocabulary (at most K * max-fanout), so the whole step lives in LDS and
+// wave64 reductions.
+#include <math.h>
+#include <string.h>
+
+#include "common.h"
+
+#define BS_THREADS 256
+#define BS_WAVES (BS_THREADS / GRX_WAVE)
+#define BS_MAXK 256
+#define BS_MAXKEEP 512
+#define BS_LDS_KEYS_MAX 16384  // 128 KiB of staged 64-bit keys at most
+
+struct BeamDerived {
+    float fin_div;    // (cur_len + 1 - prompt_len) ** length_penalty
+    float heur_div;   // best_hypothetical_length ** length_penalty
+    int lds_keys;     // capacity of the dynamic LDS key buffer (0: rescan global memory)
+};
+
+__device__ __forceinline__ unsigned long long make_key(float score, uint32_t flat) {
+    return ((unsigned long long)float_to_ordered(score) << 32) | (unsigned long long)(0xFFFFFFFFu - flat);
+}
+
+__device__ __forceinline__ bool ranks_before(float va, int ia, float vb, int ib) {
+    return va > vb || (va == vb && ia < ib);
+}
+
+__global__ __launch_bounds__(BS_THREADS) void beam_step_kernel(grx_beam_step_args a, BeamDerived d) {
+    extern __shared__ unsigned long long s_keys[];
+    __shared__ int s_pre[BS_MAXK + 1];
+    __shared__ unsigned long long s_red[2][BS_WAVES];
+    __shared__ float s_score[BS_MAXKEEP];
+    __shared__ int s_parent[BS_MAXKEEP];
+    __shared__ int s_tok[BS_MAXKEEP];
+    __shared__ unsigned char s_hit[BS_MAXKEEP];
+    __shared__ float s_rs[BS_MAXKEEP];
+    __shared__ float s_merged[BS_MAXK + BS_MAXKEEP];
+    __shared__ int s_run_idx[BS_MAXK];
+    __shared__ int s_fin_idx[BS_MAXK];
+    __shared__ float s_newfin[BS_MAXK];
+    __shared__ unsigned char s_newdone[BS_MAXK];
+
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int lane = tid & (GRX_WAVE - 1);
+    const int wave = tid / GRX_WAVE;
+    const int K = a.K, V = a.V, n_keep = a.n_keep, cmax = a.cmax;
+    const int64_t row0 = (int64_t)b * K;
+
+    // ---- candidate layout: prefix sums of the per-beam counts
+    if (tid == 0) {
+        int acc = 0;
+        for (int k = 0; k < K; ++k) {
+            s_pre[k] = acc;
+            acc += a.cand_count[row0 + k];
+        }
+        s_pre[K] = acc;
+    }
+    __syncthreads();
+    const int N = s_pre[K];
+    const bool staged = N <= d.lds_keys;
+
+    auto key_of = [&](int c) -> unsigned long long {
+        int lo = 0, hi = K;  // largest k with s_pre[k] <= c
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (s_pre[mid] <= c) lo = mid; else hi = mid;
+        }
+        const int k = lo;
+        const int64_t at = (row0 + k) * cmax + (c - s_pre[k]);
+        const float score = a.cand_logp[at] + a.run_score_in[row0 + k];
+        return make_key(score, (uint32_t)k * (uint32_t)V + (uint32_t)a.cand_tok[at]);
+    };
+
+    if (staged) {
+        for (int c = tid; c < N; c += BS_THREADS) s_keys[c] = key_of(c);
+        __syncthreads();
+    }
+
+    // ---- top n_keep by (score desc, beam * V + token asc): n_keep rounds of
+    // "largest key below the previous winner"; keys are unique.
+    unsigned long long prev = ~0ull;
+    for (int j = 0; j < n_keep; ++j) {
+        unsigned long long best = 0;
+        if (prev != 0) {
+            if (staged) {
+                for (int c = tid; c < N; c += BS_THREADS) {
+                    const unsigned long long kv = s_keys[c];
+                    if (kv < prev && kv > best) best = kv;
+                }
+            } else {
+                for (int c = tid; c < N; c += BS_THREADS) {
+                    const unsigned long long kv = key_of(c);
+                    if (kv < prev && kv > best) best = kv;
+                }
+            }
+            best = wave_max_u64(best);
+            if (lane == 0) s_red[j & 1][wave] = best;
+            __syncthreads();
+            best = s_red[j & 1][0];
+#pragma unroll
+            for (int w = 1; w < BS_WAVES; ++w) best = s_red[j & 1][w] > best ? s_red[j & 1][w] : best;
+        }
+        if (tid == 0) {
+            if (best == 0) {  // fewer candidates than n_keep: a -inf filler slot
+                s_score[j] = -INFINITY;
+                s_parent[j] = 0;
+                s_tok[j] = 0;
+            } else {
+                const uint32_t flat = 0xFFFFFFFFu - (uint32_t)(best & 0xFFFFFFFFull);
+                s_score[j] = ordered_to_float((uint32_t)(best >> 32));
+                s_parent[j] = (int)(flat / (uint32_t)V);
+                s_tok[j] = (int)(flat % (uint32_t)V);
+            }
+        }
+        prev = best;
+    }
+    __syncthreads();
+
+    // ---- stopping criteria and the two masked score vectors
+    const bool at_max_len = (a.cur_len + 1) >= a.max_length;
+    bool all_done = true;
+    for (int k = 0; k < K; ++k) all_done = all_done && (a.fin_done_in[row0 + k] != 0);
+    const bool beams_full = all_done && (a.early_stopping == 1);
+    const bool unsat_old = a.unsat[b] != 0;
+    for (int j = tid; j < n_keep; j += BS_THREADS) {
+        const bool hit = at_max_len || (a.eos_token_id >= 0 && s_tok[j] == a.eos_token_id);
+        s_hit[j] = hit ? 1 : 0;
+        const float sc = s_score[j];
+        s_rs[j] = hit ? sc + (-1.0e9f) : sc;
+        float fs = sc / d.fin_div;
+        if (beams_full) fs += -1.0e9f;
+        if (!unsat_old) fs += -1.0e9f;
+        if (!(hit && j < K)) fs += -1.0e9f;
+        s_merged[K + j] = fs;
+    }
+    for (int k = tid; k < K; k += BS_THREADS) s_merged[k] = a.fin_score_in[row0 + k];
+    __syncthreads();
+
+    // ---- running top-K (of n_keep) and finished top-K (of K + n_keep) by rank counting
+    for (int j = tid; j < n_keep; j += BS_THREADS) {
+        const float v = s_rs[j];
+        int rank = 0;
+        for (int i = 0; i < n_keep; ++i) rank += ranks_before(s_rs[i], i, v, j) ? 1 : 0;
+        if (rank < K) s_run_idx[rank] = j;
+    }
+    const int n_merged = K + n_keep;
+    for (int j = tid; j < n_merged; j += BS_THREADS) {
+        const float v = s_merged[j];
+        int rank = 0;
+        for (int i = 0; i < n_merged; ++i) rank += ranks_before(s_merged[i], i, v, j) ? 1 : 0;
+        if (rank < K) s_fin_idx[rank] = j;
+    }
+    __syncthreads();
+
+    // ---- write the per-step results
+    for (int j = tid; j < n_keep; j += BS_THREADS) {
+        const int64_t o = (int64_t)b * n_keep + j;
+        if (a.topk_score) a.topk_score[o] = s_score[j];
+        if (a.topk_parent) a.topk_parent[o] = s_parent[j];
+        if (a.topk_token) a.topk_token[o] = s_tok[j];
+        if (a.topk_hit) a.topk_hit[o] = s_hit[j];
+    }
+
+    const int L = a.max_length;
+    const int Lg = a.max_length - a.prompt_len;
+    const int gpos = a.cur_len - a.prompt_len;
+    for (int k = tid; k < K; k += BS_THREADS) {
+        const int j = s_run_idx[k];
+        a.run_score_out[row0 + k] = s_rs[j];
+        a.run_seq_out[(row0 + k) * L + a.cur_len] = (int64_t)s_tok[j];
+        a.run_bidx_out[(row0 + k) * Lg + gpos] = (int)row0 + s_parent[j];
+        if (a.next_parent) a.next_parent[row0 + k] = (int)row0 + s_parent[j];
+
+        const int m = s_fin_idx[k];
+        float fscore;
+        unsigned char fdone;
+        if (m < K) {
+            fscore = s_merged[m];
+            fdone = a.fin_done_in[row0 + m];
+        } else {
+            const int jj = m - K;
+            fscore = s_merged[m];
+            fdone = (s_hit[jj] && jj < K) ? 1 : 0;
+            a.fin_seq_out[(row0 + k) * L + a.cur_len] = (int64_t)s_tok[jj];
+            a.fin_bidx_out[(row0 + k) * Lg + gpos] = (int)row0 + s_parent[jj];
+        }
+        a.fin_score_out[row0 + k] = fscore;
+        a.fin_done_out[row0 + k] = fdone;
+        s_newfin[k] = fscore;
+        s_newdone[k] = fdone;
+    }
+
+    // sequence bodies [copy_from, cur_len) (+ position cur_len for carried-over finished rows)
+    const int w_run = a.cur_len - a.copy_from;
+    for (int idx = tid; idx < K * w_run; idx += BS_THREADS) {
+        const int k = idx / w_run, p = a.copy_from + idx % w_run;
+        const int src = s_parent[s_run_idx[k]];
+        a.run_seq_out[(row0 + k) * L + p] = a.run_seq_in[(row0 + src) * L + p];
+    }
+    const int w_fin = a.cur_len + 1 - a.copy_from;
+    for (int idx = tid; idx < K * w_fin; idx += BS_THREADS) {
+        const int k = idx / w_fin, p = a.copy_from + idx % w_fin;
+        const int m = s_fin_idx[k];
+        if (m < K) {
+            a.fin_seq_out[(row0 + k) * L + p] = a.fin_seq_in[(row0 + m) * L + p];
+        } else if (p < a.cur_len) {
+            a.fin_seq_out[(row0 + k) * L + p] = a.run_seq_in[(row0 + s_parent[m - K]) * L + p];
+        }
+    }
+    // parent trails [0, gpos) (+ position gpos for carried-over finished rows)
+    for (int idx = tid; idx < K * gpos; idx += BS_THREADS) {
+        const int k = idx / gpos, q = idx % gpos;
+        a.run_bidx_out[(row0 + k) * Lg + q] = a.run_bidx_in[(row0 + s_parent[s_run_idx[k]]) * Lg + q];
+    }
+    for (int idx = tid; idx < K * (gpos + 1); idx += BS_THREADS) {
+        const int k = idx / (gpos + 1), q = idx % (gpos + 1);
+        const int m = s_fin_idx[k];
+        if (m < K) {
+            a.fin_bidx_out[(row0 + k) * Lg + q] = a.fin_bidx_in[(row0 + m) * Lg + q];
+        } else if (q < gpos) {
+            a.fin_bidx_out[(row0 + k) * Lg + q] = a.run_bidx_in[(row0 + s_parent[m - K]) * Lg + q];
+        }
+    }
+    __syncthreads();
+
+    // ---- early-stop heuristic for the next iteration
+    if (tid == 0) {
+        const float best_possible = s_rs[s_run_idx[0]] / d.heur_div;
+        float worst_all = s_newfin[0];
+        for (int k = 1; k < K; ++k) worst_all = fminf(worst_all, s_newfin[k]);
+        bool any = false;
+        for (int k = 0; k < K; ++k) {
+            const float worst = s_newdone[k] ? worst_all : -1.0e9f;
+            any = any || (best_possible > worst);
+        }
+        a.unsat[b] = (unsat_old && any) ? 1 : 0;
+    }
+}
+
+extern "C" int grx_beam_step(const grx_beam_step_args* args, void* stream) {
+    const char* who = "grx_beam_step";
+    GRX_REQUIRE(args != nullptr, GRX_E_INVALID, "%s: null args", who);
+    const grx_beam_step_args& a = *args;
+    GRX_REQUIRE(a.B >= 0 && a.K >= 1 && a.V >= 1 && a.cmax >= 1, GRX_E_INVALID, "%s: bad shape", who);
+    GRX_REQUIRE(a.K <= BS_MAXK && a.n_keep <= BS_MAXKEEP, GRX_E_UNSUPPORTED,
+                "%s: supports at most %d beams and %d kept candidates", who, BS_MAXK, BS_MAXKEEP);
+    GRX_REQUIRE(a.n_keep >= a.K, GRX_E_INVALID, "%s: n_keep must be >= K", who);
+    GRX_REQUIRE((uint64_t)a.K * (uint64_t)a.V <= 0xFFFFFFFFull, GRX_E_UNSUPPORTED, "%s: K * V exceeds 32 bits", who);
+    GRX_REQUIRE(a.prompt_len >= 0 && a.cur_len >= a.prompt_len && a.cur_len < a.max_length, GRX_E_INVALID,
+                "%s: need prompt_len <= cur_len < max_length", who);
+    GRX_REQUIRE(a.copy_from >= 0 && a.copy_from <= a.cur_len, GRX_E_INVALID, "%s: bad copy_from", who);
+    GRX_REQUIRE(a.early_stopping >= 0 && a.early_stopping <= 2, GRX_E_INVALID, "%s: bad early_stopping", who);
+    if (a.B == 0) return GRX_OK;
+    GRX_REQUIRE(a.cand_count && a.cand_tok && a.cand_logp && a.run_seq_in && a.run_seq_out && a.run_score_in &&
+                    a.run_score_out && a.run_bidx_in && a.run_bidx_out && a.fin_seq_in && a.fin_seq_out &&
+                    a.fin_score_in && a.fin_score_out && a.fin_bidx_in && a.fin_bidx_out && a.fin_done_in &&
+                    a.fin_done_out && a.unsat,
+                GRX_E_INVALID, "%s: null buffer", who);
+    GRX_REQUIRE(a.run_seq_in != a.run_seq_out && a.fin_seq_in != a.fin_seq_out && a.run_score_in != a.run_score_out &&
+                    a.fin_score_in != a.fin_score_out && a.run_bidx_in != a.run_bidx_out &&
+                    a.fin_bidx_in != a.fin_bidx_out && a.fin_done_in != a.fin_done_out,
+                GRX_E_INVALID, "%s: in and out buffers must differ", who);
+
+    BeamDerived d;
+    const double lp = (double)a.length_penalty;
+    d.fin_div = (float)pow((double)(a.cur_len + 1 - a.prompt_len), lp);
+    const int hyp = (a.early_stopping == 2 && a.length_penalty > 0.0f) ? (a.max_length - a.prompt_len)
+                                                                       : (a.cur_len + 1 - a.prompt_len);
+    d.heur_div = (float)pow((double)hyp, lp);
+    int keys = 1;
+    const int64_t worst = (int64_t)a.K * a.cmax;
+    while (keys < worst && keys < BS_LDS_KEYS_MAX) keys <<= 1;
+    d.lds_keys = keys;
+    const size_t lds_bytes = (size_t)keys * sizeof(unsigned long long);
+    if (lds_bytes > 48 * 1024) {
+        GRX_CHECK_HIP(hipFuncSetAttribute((const void*)beam_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)lds_bytes));
+    }
+    hipLaunchKernelGGL(beam_step_kernel, dim3(a.B), dim3(BS_THREADS), lds_bytes, (hipStream_t)stream, a, d);
+    GRX_CHECK_HIP(hipGetLastError());
+    return GRX_OK;
+}

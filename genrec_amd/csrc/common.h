@@ -1,0 +1,138 @@
+// Internal helpers shared by the kernels of libgenrec_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "genrec_hip.h"
+
+#define GRX_WAVE 64
+
+// ---------------------------------------------------------------- errors ---
+void grx_set_error(const char* fmt, ...);
+
+#define GRX_CHECK_HIP(expr)                                                                   \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) {                                                               \
+            grx_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return GRX_E_HIP;                                                                 \
+        }                                                                                     \
+    } while (0)
+
+#define GRX_REQUIRE(cond, code, ...)    \
+    do {                                \
+        if (!(cond)) {                  \
+            grx_set_error(__VA_ARGS__); \
+            return (code);              \
+        }                               \
+    } while (0)
+
+// ------------------------------------------------------- opaque handles ---
+struct grx_trie {
+    int32_t* child_off;  // device [n_nodes + 1]
+    int32_t* child_tok;  // device [n_edges]
+    int32_t n_nodes;
+    int32_t n_edges;
+    int32_t max_fanout;
+    int32_t max_token;
+    int device;
+};
+
+// Device words behind grx_state.
+struct grx_state_words {
+    int32_t count;            // shared step counter of the count-based processor
+    int32_t first_match;      // lowest row whose tail equals prefix_ids in the current call
+    uint32_t err;             // 0xFFFFFFFF = none, else (row << 2) | GRX_ROWERR_*
+    int32_t calls;            // number of processor calls finished
+};
+
+struct grx_state {
+    grx_state_words* dev;
+    int device;
+};
+
+#define GRX_NO_MATCH 0x7FFFFFFF
+#define GRX_NO_ERR 0xFFFFFFFFu
+
+// Row resolution results stored in the workspace (int32 per row).
+#define GRX_RES_EMPTY (-1)    // trie.get(...) == []            -> GRX_ROWERR_EMPTY
+#define GRX_RES_EOS (-2)      // row ends in EOS                -> allowed = {eos}
+#define GRX_RES_NOMATCH (-3)  // no valid prefix occurrence     -> GRX_ROWERR_NOMATCH
+
+// ------------------------------------------------------ device helpers ---
+struct TrieView {
+    const int32_t* __restrict__ off;
+    const int32_t* __restrict__ tok;
+};
+
+// Child of `node` along token `t`, or -1.  Binary search over the node's
+// ascending token list.
+__device__ __forceinline__ int trie_child(const TrieView& tv, int node, int64_t t) {
+    if (t < 0 || t > 0x7FFFFFFFLL) return -1;
+    const int32_t key = (int32_t)t;
+    int lo = tv.off[node];
+    const int end = tv.off[node + 1];
+    int hi = end;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (tv.tok[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return (lo < end && tv.tok[lo] == key) ? lo + 1 : -1;
+}
+
+// Node reached from the root along ids[0..n), or GRX_RES_EMPTY when the path
+// leaves the trie or ends on a node without children (Trie.get returns []).
+__device__ __forceinline__ int trie_walk(const TrieView& tv, const int64_t* __restrict__ ids, int n) {
+    int node = 0;
+    for (int i = 0; i < n; ++i) {
+        node = trie_child(tv, node, ids[i]);
+        if (node < 0) return GRX_RES_EMPTY;
+    }
+    return (tv.off[node + 1] > tv.off[node]) ? node : GRX_RES_EMPTY;
+}
+
+// Start index of the Python slice sent[-k:] on a row of T tokens.
+__device__ __forceinline__ int py_tail_start(int k, int T) {
+    if (k > 0) return (T - k > 0) ? T - k : 0;
+    const int s = -k;
+    return s < T ? s : T;
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, GRX_WAVE));
+    return v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, GRX_WAVE);
+    return v;
+}
+
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned lo = __shfl_xor((unsigned)(v & 0xFFFFFFFFull), o, GRX_WAVE);
+        const unsigned hi = __shfl_xor((unsigned)(v >> 32), o, GRX_WAVE);
+        const unsigned long long w = ((unsigned long long)hi << 32) | lo;
+        v = w > v ? w : v;
+    }
+    return v;
+}
+
+// Monotone map float -> uint32 (larger float => larger integer; -0 < +0).
+__device__ __forceinline__ uint32_t float_to_ordered(float f) {
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ordered_to_float(uint32_t o) {
+    const uint32_t u = (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o;
+    return __uint_as_float(u);
+}
+
+__device__ __forceinline__ void report_row_error(grx_state_words* st, int row, int code) {
+    if (st) atomicMin(&st->err, ((uint32_t)row << 2) | (uint32_t)code);
+}

@@ -1,0 +1,372 @@
+// Masked log-softmax over logit rows: the HBM-bound pass of the constrained
+// decoding step.  One 256-thread workgroup streams one row exactly once with
+// 16-byte loads, keeping an online (max, sum-of-exp) pair per thread; the
+// allowed tokens of the row (children of its trie node) are gathered while the
+// stream is in flight and finished once the row's log-sum-exp is known.
+#include <hip/hip_bf16.h>
+#include <hip/hip_fp16.h>
+#include <math.h>
+#include <string.h>
+
+#include "common.h"
+#include "resolve.h"
+
+#define MLS_THREADS 256
+#define MLS_WAVES (MLS_THREADS / GRX_WAVE)
+#define MLS_UNROLL 4      // 16-byte loads in flight per thread
+#define MLS_EARLY 2       // allowed tokens gathered per thread before the stream
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+enum { OUT_COMPACT = 0, OUT_FULL_F32 = 1, OUT_FULL_SAME = 2 };
+
+struct MlsArgs {
+    TrieView tv;
+    grx_state_words* st;   // may be null (fixed-hint without error reporting)
+    const int32_t* res;    // [2R] resolution results
+    int R;
+    const void* scores;
+    int64_t scores_stride;
+    int V;
+    int eos;
+    void* out;             // full modes
+    int64_t out_stride;
+    int32_t* cand_count;   // compact mode
+    int32_t* cand_tok;
+    float* cand_logp;
+    int cmax;
+};
+
+static constexpr float kLog2e = 1.4426950408889634f;
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// ---- element traits --------------------------------------------------------
+template <int DT> struct Elem;
+template <> struct Elem<GRX_F32> {
+    typedef float T;
+    static constexpr int kPerVec = 4;
+    static __device__ __forceinline__ float to_float(float v) { return v; }
+    static __device__ __forceinline__ void unpack(const u32x4& v, float* f) {
+        f[0] = __uint_as_float(v.x); f[1] = __uint_as_float(v.y);
+        f[2] = __uint_as_float(v.z); f[3] = __uint_as_float(v.w);
+    }
+    static __device__ __forceinline__ float from_float(float v) { return v; }
+    static constexpr uint32_t kNegInfPacked = 0xFF800000u;
+};
+template <> struct Elem<GRX_BF16> {
+    typedef uint16_t T;
+    static constexpr int kPerVec = 8;
+    static __device__ __forceinline__ float to_float(uint16_t v) { return __uint_as_float((uint32_t)v << 16); }
+    static __device__ __forceinline__ void unpack(const u32x4& v, float* f) {
+        f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xFFFF0000u);
+        f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xFFFF0000u);
+        f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xFFFF0000u);
+        f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xFFFF0000u);
+    }
+    static __device__ __forceinline__ uint16_t from_float(float v) {
+        __hip_bfloat16 b = __float2bfloat16(v);
+        return *reinterpret_cast<uint16_t*>(&b);
+    }
+    static constexpr uint32_t kNegInfPacked = 0xFF80FF80u;
+};
+template <> struct Elem<GRX_F16> {
+    typedef uint16_t T;
+    static constexpr int kPerVec = 8;
+    static __device__ __forceinline__ float to_float(uint16_t v) {
+        __half h = *reinterpret_cast<__half*>(&v);
+        return __half2float(h);
+    }
+    static __device__ __forceinline__ void unpack(const u32x4& v, float* f) {
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f[2 * i] = to_float((uint16_t)(w[i] & 0xFFFFu));
+            f[2 * i + 1] = to_float((uint16_t)(w[i] >> 16));
+        }
+    }
+    static __device__ __forceinline__ uint16_t from_float(float v) {
+        __half h = __float2half(v);
+        return *reinterpret_cast<uint16_t*>(&h);
+    }
+    static constexpr uint32_t kNegInfPacked = 0xFC00FC00u;
+};
+
+// ---- online softmax accumulator ---------------------------------------------
+struct MaxSum {
+    float m, s;
+};
+
+template <int N>
+__device__ __forceinline__ void accumulate(MaxSum& a, const float* v) {
+    float cm = v[0];
+#pragma unroll
+    for (int j = 1; j < N; ++j) cm = fmaxf(cm, v[j]);
+    const float mn = fmaxf(a.m, cm);
+    const float mref = (mn == -INFINITY) ? 0.f : mn;
+    float acc0 = 0.f, acc1 = 0.f;
+#pragma unroll
+    for (int j = 0; j + 1 < N; j += 2) {
+        acc0 += fast_exp2((v[j] - mref) * kLog2e);
+        acc1 += fast_exp2((v[j + 1] - mref) * kLog2e);
+    }
+    if (N & 1) acc0 += fast_exp2((v[N - 1] - mref) * kLog2e);
+    a.s = a.s * fast_exp2((a.m - mref) * kLog2e) + (acc0 + acc1);
+    a.m = mn;
+}
+
+__device__ __forceinline__ MaxSum block_combine(MaxSum a, float* s_m, float* s_s) {
+    const int lane = threadIdx.x & (GRX_WAVE - 1);
+    const int wave = threadIdx.x / GRX_WAVE;
+    float M = wave_max(a.m);
+    float Mref = (M == -INFINITY) ? 0.f : M;
+    float S = wave_sum(a.s * fast_exp2((a.m - Mref) * kLog2e));
+    if (lane == 0) {
+        s_m[wave] = M;
+        s_s[wave] = S;
+    }
+    __syncthreads();
+    float bm = s_m[0];
+#pragma unroll
+    for (int w = 1; w < MLS_WAVES; ++w) bm = fmaxf(bm, s_m[w]);
+    const float bref = (bm == -INFINITY) ? 0.f : bm;
+    float bs = 0.f;
+#pragma unroll
+    for (int w = 0; w < MLS_WAVES; ++w) bs += s_s[w] * fast_exp2((s_m[w] - bref) * kLog2e);
+    MaxSum r;
+    r.m = bm;
+    r.s = bs;
+    return r;
+}
+
+// ---- the kernel --------------------------------------------------------------
+// DT: element type of the logits.  OUT: OUT_*.  VEC: rows (and, for the full
+// modes, output rows) are 16-byte aligned so the stream uses 16-byte accesses;
+// otherwise one element per access.
+template <int DT, int OUT, bool VEC>
+__global__ __launch_bounds__(MLS_THREADS) void masked_lsm_kernel(MlsArgs a) {
+    typedef Elem<DT> E;
+    typedef typename E::T T;
+    constexpr int EPV = VEC ? E::kPerVec : 1;  // elements per access
+    __shared__ float s_m[MLS_WAVES], s_s[MLS_WAVES];
+
+    const int r = blockIdx.x;
+    const int tid = threadIdx.x;
+    const T* __restrict__ row = reinterpret_cast<const T*>(a.scores) + (int64_t)r * a.scores_stride;
+
+    // Which trie node governs this row.
+    const int fm = a.st ? a.st->first_match : GRX_NO_MATCH;
+    const int code = a.res[(r >= fm ? a.R : 0) + r];
+    int c_off = 0, c_n = 0;
+    if (code >= 0) {
+        c_off = a.tv.off[code];
+        c_n = a.tv.off[code + 1] - c_off;
+    } else if (code == GRX_RES_EOS) {
+        c_n = 1;
+    } else if (tid == 0) {
+        report_row_error(a.st, r, code == GRX_RES_NOMATCH ? GRX_ROWERR_NOMATCH : GRX_ROWERR_EMPTY);
+    }
+    if (OUT == OUT_COMPACT && c_n > a.cmax) {
+        if (tid == 0) report_row_error(a.st, r, GRX_ROWERR_OVERFLOW);
+        c_n = 0;
+    }
+
+    // Gather the first allowed logits now so they overlap the stream.
+    int e_tok[MLS_EARLY];
+    float e_val[MLS_EARLY];
+#pragma unroll
+    for (int k = 0; k < MLS_EARLY; ++k) {
+        const int i = tid + k * MLS_THREADS;
+        e_tok[k] = -1;
+        e_val[k] = 0.f;
+        if (i < c_n) {
+            e_tok[k] = (code == GRX_RES_EOS) ? a.eos : a.tv.tok[c_off + i];
+            e_val[k] = E::to_float(row[e_tok[k]]);
+        }
+    }
+
+    // Stream the row once.
+    MaxSum acc;
+    acc.m = -INFINITY;
+    acc.s = 0.f;
+    const int nvec = a.V / EPV;
+
+    if (VEC) {
+        const u32x4* __restrict__ vp = reinterpret_cast<const u32x4*>(row);
+        u32x4* __restrict__ op = nullptr;
+        if (OUT != OUT_COMPACT) {
+            const size_t osz = (OUT == OUT_FULL_F32) ? sizeof(float) : sizeof(T);
+            op = reinterpret_cast<u32x4*>(reinterpret_cast<char*>(a.out) + (int64_t)r * a.out_stride * osz);
+        }
+        const uint32_t ninf = (OUT == OUT_FULL_F32) ? 0xFF800000u : E::kNegInfPacked;
+        const u32x4 fill = {ninf, ninf, ninf, ninf};
+        // 16-byte output vectors written per input vector
+        constexpr int OPV = (OUT == OUT_FULL_F32) ? (E::kPerVec * 4) / 16 : 1;
+
+        int i = tid;
+        for (; i + (MLS_UNROLL - 1) * MLS_THREADS < nvec; i += MLS_UNROLL * MLS_THREADS) {
+            u32x4 v[MLS_UNROLL];
+#pragma unroll
+            for (int u = 0; u < MLS_UNROLL; ++u) v[u] = vp[i + u * MLS_THREADS];
+            if (OUT != OUT_COMPACT) {
+#pragma unroll
+                for (int u = 0; u < MLS_UNROLL; ++u)
+#pragma unroll
+                    for (int o = 0; o < OPV; ++o) op[(int64_t)(i + u * MLS_THREADS) * OPV + o] = fill;
+            }
+            float f[MLS_UNROLL * E::kPerVec];
+#pragma unroll
+            for (int u = 0; u < MLS_UNROLL; ++u) E::unpack(v[u], f + u * E::kPerVec);
+            accumulate<MLS_UNROLL * E::kPerVec>(acc, f);
+        }
+        for (; i < nvec; i += MLS_THREADS) {
+            const u32x4 v = vp[i];
+            if (OUT != OUT_COMPACT) {
+#pragma unroll
+                for (int o = 0; o < OPV; ++o) op[(int64_t)i * OPV + o] = fill;
+            }
+            float f[E::kPerVec];
+            E::unpack(v, f);
+            accumulate<E::kPerVec>(acc, f);
+        }
+    }
+    // Elements not covered by 16-byte vectors (all of them when !VEC).
+    {
+        const float ninf_f = -INFINITY;
+        for (int e = (VEC ? nvec * EPV : 0) + tid; e < a.V; e += MLS_THREADS) {
+            float f[1] = {E::to_float(row[e])};
+            accumulate<1>(acc, f);
+            if (OUT == OUT_FULL_F32) {
+                reinterpret_cast<float*>(a.out)[(int64_t)r * a.out_stride + e] = ninf_f;
+            } else if (OUT == OUT_FULL_SAME) {
+                reinterpret_cast<T*>(a.out)[(int64_t)r * a.out_stride + e] = E::from_float(ninf_f);
+            }
+        }
+    }
+
+    if (OUT != OUT_COMPACT) {
+        // The -inf fill of every thread must have reached memory before any
+        // thread overwrites an allowed position.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    const MaxSum tot = block_combine(acc, s_m, s_s);  // contains a workgroup barrier
+    const float log_s = logf(tot.s);
+
+    // Emit the allowed tokens.
+#pragma unroll
+    for (int k = 0; k < MLS_EARLY; ++k) {
+        const int i = tid + k * MLS_THREADS;
+        if (i < c_n) {
+            const float lp = (e_val[k] - tot.m) - log_s;
+            if (OUT == OUT_COMPACT) {
+                a.cand_tok[(int64_t)r * a.cmax + i] = e_tok[k];
+                a.cand_logp[(int64_t)r * a.cmax + i] = lp;
+            } else if (OUT == OUT_FULL_F32) {
+                reinterpret_cast<float*>(a.out)[(int64_t)r * a.out_stride + e_tok[k]] = lp;
+            } else {
+                reinterpret_cast<T*>(a.out)[(int64_t)r * a.out_stride + e_tok[k]] = E::from_float(lp);
+            }
+        }
+    }
+    for (int i = tid + MLS_EARLY * MLS_THREADS; i < c_n; i += MLS_THREADS) {
+        const int tok = a.tv.tok[c_off + i];  // an EOS-only row has c_n == 1 and never gets here
+        const float lp = (E::to_float(row[tok]) - tot.m) - log_s;
+        if (OUT == OUT_COMPACT) {
+            a.cand_tok[(int64_t)r * a.cmax + i] = tok;
+            a.cand_logp[(int64_t)r * a.cmax + i] = lp;
+        } else if (OUT == OUT_FULL_F32) {
+            reinterpret_cast<float*>(a.out)[(int64_t)r * a.out_stride + tok] = lp;
+        } else {
+            reinterpret_cast<T*>(a.out)[(int64_t)r * a.out_stride + tok] = E::from_float(lp);
+        }
+    }
+    if (OUT == OUT_COMPACT && tid == 0) a.cand_count[r] = c_n;
+}
+
+// ---- launch -------------------------------------------------------------------
+template <int DT, int OUT>
+static void launch_vec(bool vec, const MlsArgs& a, hipStream_t stream) {
+    if (vec)
+        hipLaunchKernelGGL((masked_lsm_kernel<DT, OUT, true>), dim3(a.R), dim3(MLS_THREADS), 0, stream, a);
+    else
+        hipLaunchKernelGGL((masked_lsm_kernel<DT, OUT, false>), dim3(a.R), dim3(MLS_THREADS), 0, stream, a);
+}
+
+template <int OUT>
+static void launch_dtype(int dtype, bool vec, const MlsArgs& a, hipStream_t stream) {
+    if (dtype == GRX_F32) launch_vec<GRX_F32, OUT>(vec, a, stream);
+    else if (dtype == GRX_BF16) launch_vec<GRX_BF16, OUT>(vec, a, stream);
+    else launch_vec<GRX_F16, OUT>(vec, a, stream);
+}
+
+static size_t dtype_size(int dt) { return dt == GRX_F32 ? 4 : 2; }
+
+static bool rows_16b_aligned(const void* base, int64_t stride, size_t elsize) {
+    return (((uintptr_t)base) & 15u) == 0 && ((stride * (int64_t)elsize) & 15) == 0;
+}
+
+static int run_step(const char* who, const grx_trie* trie, grx_state* state, const grx_rows* rows,
+                    const grx_constraint* con, MlsArgs& a, int out_kind, bool out_aligned, void* workspace,
+                    size_t workspace_bytes, hipStream_t stream) {
+    int rc = grx_check_step_args(who, trie, state, rows, con, workspace, workspace_bytes);
+    if (rc != GRX_OK) return rc;
+    GRX_REQUIRE(con->eos_token_id < rows->V, GRX_E_INVALID, "%s: eos_token_id %d outside V=%d", who,
+                con->eos_token_id, rows->V);
+    if (rows->R == 0) return grx_state_advance(state, con->mode == GRX_MODE_COUNT, stream);
+
+    int32_t* res = reinterpret_cast<int32_t*>(workspace);
+    rc = grx_resolve_rows(trie, state, rows, con, res, stream);
+    if (rc != GRX_OK) return rc;
+
+    a.tv = TrieView{trie->child_off, trie->child_tok};
+    a.st = state ? state->dev : nullptr;
+    a.res = res;
+    a.R = rows->R;
+    a.scores = rows->scores;
+    a.scores_stride = rows->scores_stride;
+    a.V = rows->V;
+    a.eos = con->eos_token_id;
+    const bool vec = rows_16b_aligned(rows->scores, rows->scores_stride, dtype_size(rows->dtype)) && out_aligned;
+    if (out_kind == OUT_COMPACT) launch_dtype<OUT_COMPACT>(rows->dtype, vec, a, stream);
+    else if (out_kind == OUT_FULL_F32) launch_dtype<OUT_FULL_F32>(rows->dtype, vec, a, stream);
+    else launch_dtype<OUT_FULL_SAME>(rows->dtype, vec, a, stream);
+    GRX_CHECK_HIP(hipGetLastError());
+    return grx_state_advance(state, con->mode == GRX_MODE_COUNT, stream);
+}
+
+extern "C" int grx_constrained_logsoftmax(const grx_trie* trie, grx_state* state, const grx_rows* rows,
+                                          const grx_constraint* con, void* out, int64_t out_stride,
+                                          int32_t out_dtype, void* workspace, size_t workspace_bytes, void* stream) {
+    const char* who = "grx_constrained_logsoftmax";
+    GRX_REQUIRE(rows != nullptr, GRX_E_INVALID, "%s: null rows", who);
+    GRX_REQUIRE(out_dtype == GRX_F32 || out_dtype == rows->dtype, GRX_E_UNSUPPORTED,
+                "%s: output must be fp32 or the input element type", who);
+    GRX_REQUIRE(rows->R == 0 || (out != nullptr && out_stride >= rows->V), GRX_E_INVALID, "%s: bad output", who);
+    GRX_REQUIRE(out != rows->scores || rows->R == 0, GRX_E_INVALID, "%s: out must not alias scores", who);
+    MlsArgs a;
+    memset(&a, 0, sizeof(a));
+    a.out = out;
+    a.out_stride = out_stride;
+    const int kind = (out_dtype == GRX_F32) ? OUT_FULL_F32 : OUT_FULL_SAME;
+    const bool out_aligned = rows_16b_aligned(out, out_stride, dtype_size(out_dtype));
+    return run_step(who, trie, state, rows, con, a, kind, out_aligned, workspace, workspace_bytes,
+                    (hipStream_t)stream);
+}
+
+extern "C" int grx_constrained_candidates(const grx_trie* trie, grx_state* state, const grx_rows* rows,
+                                          const grx_constraint* con, int32_t* cand_count, int32_t* cand_tok,
+                                          float* cand_logp, int32_t cmax, void* workspace, size_t workspace_bytes,
+                                          void* stream) {
+    const char* who = "grx_constrained_candidates";
+    GRX_REQUIRE(rows != nullptr, GRX_E_INVALID, "%s: null rows", who);
+    GRX_REQUIRE(cmax >= 1, GRX_E_INVALID, "%s: cmax must be >= 1", who);
+    GRX_REQUIRE(rows->R == 0 || (cand_count && cand_tok && cand_logp), GRX_E_INVALID, "%s: null output", who);
+    MlsArgs a;
+    memset(&a, 0, sizeof(a));
+    a.cand_count = cand_count;
+    a.cand_tok = cand_tok;
+    a.cand_logp = cand_logp;
+    a.cmax = cmax;
+    return run_step(who, trie, state, rows, con, a, OUT_COMPACT, true, workspace, workspace_bytes,
+                    (hipStream_t)stream);
+}

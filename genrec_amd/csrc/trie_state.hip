@@ -1,0 +1,295 @@
+// Trie upload, device-resident processor state, and the per-row resolution of
+// the allowed-token node (integer work, one pass over the token rows).
+#include <stdarg.h>
+#include <string.h>
+
+#include <vector>
+
+#include "common.h"
+#include "resolve.h"
+
+// ---------------------------------------------------------------- errors ---
+static thread_local char g_err[512] = "";
+
+void grx_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* grx_last_error(void) { return g_err; }
+extern "C" int grx_abi_version(void) { return GRX_ABI_VERSION; }
+
+// ------------------------------------------------------------------ trie ---
+extern "C" int grx_trie_create(const int32_t* child_off, const int32_t* child_tok, int32_t n_nodes,
+                               int32_t n_edges, grx_trie** out) {
+    GRX_REQUIRE(out != nullptr && child_off != nullptr, GRX_E_INVALID, "grx_trie_create: null pointer");
+    GRX_REQUIRE(n_nodes >= 1 && n_edges >= 0 && n_nodes == n_edges + 1, GRX_E_INVALID,
+                "grx_trie_create: need n_nodes == n_edges + 1 >= 1 (got %d nodes, %d edges)", n_nodes, n_edges);
+    GRX_REQUIRE(n_edges == 0 || child_tok != nullptr, GRX_E_INVALID, "grx_trie_create: null child_tok");
+    GRX_REQUIRE(child_off[0] == 0 && child_off[n_nodes] == n_edges, GRX_E_INVALID,
+                "grx_trie_create: child_off must start at 0 and end at n_edges");
+    int32_t max_fanout = 0, max_token = -1;
+    for (int32_t n = 0; n < n_nodes; ++n) {
+        const int32_t a = child_off[n], b = child_off[n + 1];
+        GRX_REQUIRE(a <= b && b <= n_edges, GRX_E_INVALID, "grx_trie_create: child_off not monotone at node %d", n);
+        for (int32_t e = a; e < b; ++e) {
+            GRX_REQUIRE(child_tok[e] >= 0, GRX_E_INVALID, "grx_trie_create: negative token on edge %d", e);
+            GRX_REQUIRE(e == a || child_tok[e - 1] < child_tok[e], GRX_E_INVALID,
+                        "grx_trie_create: tokens of node %d are not strictly increasing", n);
+            // children are numbered after their parent, so a walk always terminates
+            GRX_REQUIRE(e + 1 > n, GRX_E_INVALID, "grx_trie_create: edge %d points backwards", e);
+            if (child_tok[e] > max_token) max_token = child_tok[e];
+        }
+        if (b - a > max_fanout) max_fanout = b - a;
+    }
+    grx_trie* t = new grx_trie();
+    memset(t, 0, sizeof(*t));
+    t->n_nodes = n_nodes;
+    t->n_edges = n_edges;
+    t->max_fanout = max_fanout;
+    t->max_token = max_token;
+    hipError_t e = hipGetDevice(&t->device);
+    if (e == hipSuccess) e = hipMalloc((void**)&t->child_off, sizeof(int32_t) * (size_t)(n_nodes + 1));
+    if (e == hipSuccess) e = hipMalloc((void**)&t->child_tok, sizeof(int32_t) * (size_t)(n_edges > 0 ? n_edges : 1));
+    if (e == hipSuccess)
+        e = hipMemcpy(t->child_off, child_off, sizeof(int32_t) * (size_t)(n_nodes + 1), hipMemcpyHostToDevice);
+    if (e == hipSuccess && n_edges > 0)
+        e = hipMemcpy(t->child_tok, child_tok, sizeof(int32_t) * (size_t)n_edges, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        grx_set_error("grx_trie_create: %s", hipGetErrorString(e));
+        if (t->child_off) (void)hipFree(t->child_off);
+        if (t->child_tok) (void)hipFree(t->child_tok);
+        delete t;
+        return GRX_E_HIP;
+    }
+    *out = t;
+    return GRX_OK;
+}
+
+extern "C" int grx_trie_destroy(grx_trie* t) {
+    if (!t) return GRX_OK;
+    (void)hipFree(t->child_off);
+    (void)hipFree(t->child_tok);
+    delete t;
+    return GRX_OK;
+}
+
+extern "C" int32_t grx_trie_max_fanout(const grx_trie* t) { return t ? t->max_fanout : 0; }
+extern "C" int32_t grx_trie_max_token(const grx_trie* t) { return t ? t->max_token : -1; }
+
+// ----------------------------------------------------------------- state ---
+__global__ void state_set_kernel(grx_state_words* st, int set_count, int32_t count, int clear_err) {
+    if (set_count) st->count = count;
+    if (clear_err) st->err = GRX_NO_ERR;
+}
+
+extern "C" int grx_state_create(grx_state** out) {
+    GRX_REQUIRE(out != nullptr, GRX_E_INVALID, "grx_state_create: null pointer");
+    grx_state* s = new grx_state();
+    s->dev = nullptr;
+    hipError_t e = hipGetDevice(&s->device);
+    if (e == hipSuccess) e = hipMalloc((void**)&s->dev, sizeof(grx_state_words));
+    if (e == hipSuccess) {
+        grx_state_words init = {0, GRX_NO_MATCH, GRX_NO_ERR, 0};
+        e = hipMemcpy(s->dev, &init, sizeof(init), hipMemcpyHostToDevice);
+    }
+    if (e != hipSuccess) {
+        grx_set_error("grx_state_create: %s", hipGetErrorString(e));
+        if (s->dev) (void)hipFree(s->dev);
+        delete s;
+        return GRX_E_HIP;
+    }
+    *out = s;
+    return GRX_OK;
+}
+
+extern "C" int grx_state_destroy(grx_state* s) {
+    if (!s) return GRX_OK;
+    (void)hipFree(s->dev);
+    delete s;
+    return GRX_OK;
+}
+
+extern "C" int grx_state_set_count(grx_state* s, int32_t count, void* stream) {
+    GRX_REQUIRE(s != nullptr, GRX_E_INVALID, "grx_state_set_count: null state");
+    hipLaunchKernelGGL(state_set_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, s->dev, 1, count, 0);
+    GRX_CHECK_HIP(hipGetLastError());
+    return GRX_OK;
+}
+
+extern "C" int grx_state_clear_error(grx_state* s, void* stream) {
+    GRX_REQUIRE(s != nullptr, GRX_E_INVALID, "grx_state_clear_error: null state");
+    hipLaunchKernelGGL(state_set_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, s->dev, 0, 0, 1);
+    GRX_CHECK_HIP(hipGetLastError());
+    return GRX_OK;
+}
+
+extern "C" int grx_state_read(grx_state* s, int32_t out[4], void* stream) {
+    GRX_REQUIRE(s != nullptr && out != nullptr, GRX_E_INVALID, "grx_state_read: null pointer");
+    grx_state_words w;
+    GRX_CHECK_HIP(hipMemcpyAsync(&w, s->dev, sizeof(w), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    GRX_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+    out[0] = w.count;
+    if (w.err == GRX_NO_ERR) {
+        out[1] = GRX_ROWERR_NONE;
+        out[2] = -1;
+    } else {
+        out[1] = (int32_t)(w.err & 3u);
+        out[2] = (int32_t)(w.err >> 2);
+    }
+    out[3] = w.calls;
+    return GRX_OK;
+}
+
+// --------------------------------------------------------------- resolve ---
+struct PrefixArg {
+    int32_t n;  // -1 = None
+    int64_t ids[GRX_MAX_PREFIX];
+};
+
+// Count-based window (logit_processor.py:37-42).  One thread per row.  Writes
+// two candidates per row: res[r] for the window prefix_index + count and
+// res[R + r] for the window prefix_index (count reset to 0); the consumer picks
+// the second for rows at or after the first row whose tail equals prefix_ids,
+// which is where the reference's shared counter drops to zero mid-loop.
+__global__ void resolve_count_kernel(TrieView tv, grx_state_words* st, const int64_t* __restrict__ ids,
+                                     int64_t ids_stride, int R, int T, PrefixArg pfx, int prefix_index,
+                                     int32_t* __restrict__ res) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const int64_t* row = ids + (int64_t)r * ids_stride;
+    const int count = st->count;
+
+    const int s0 = py_tail_start(prefix_index, T);
+    int node0 = GRX_RES_EMPTY;
+    if (pfx.n >= 0) {
+        bool match = (T - s0) == pfx.n;
+        for (int i = 0; match && i < pfx.n; ++i) match = row[s0 + i] == pfx.ids[i];
+        if (match) atomicMin(&st->first_match, r);
+        node0 = trie_walk(tv, row + s0, T - s0);
+    }
+    int nodeC;
+    if (count == 0 && pfx.n >= 0) {
+        nodeC = node0;
+    } else {
+        const int sc = py_tail_start(prefix_index + count, T);
+        nodeC = trie_walk(tv, row + sc, T - sc);
+    }
+    res[r] = nodeC;
+    res[R + r] = (pfx.n >= 0) ? node0 : nodeC;
+}
+
+// Fixed-hint resolution (fixed_hint_logit_processor.py:18-61).  One wave per
+// row: 64 start positions are tested for the prefix at a time, and the
+// occurrences are tried left to right until one continues inside the trie.
+__global__ void resolve_fixed_kernel(TrieView tv, const int64_t* __restrict__ ids, int64_t ids_stride, int R,
+                                     int T, PrefixArg pfx, int eos, int32_t* __restrict__ res) {
+    const int lane = threadIdx.x & (GRX_WAVE - 1);
+    const int r = (blockIdx.x * blockDim.x + threadIdx.x) / GRX_WAVE;
+    if (r >= R) return;  // wave-uniform
+    const int64_t* row = ids + (int64_t)r * ids_stride;
+
+    int out;
+    if (eos >= 0 && T > 0 && row[T - 1] == (int64_t)eos) {
+        out = GRX_RES_EOS;
+    } else if (pfx.n <= 0) {
+        out = trie_walk(tv, row, T);  // start = 0 when prefix_ids is empty or None
+    } else {
+        out = GRX_RES_NOMATCH;
+        const int n = pfx.n;
+        for (int base = 0; base + n <= T && out == GRX_RES_NOMATCH; base += GRX_WAVE) {
+            const int s = base + lane;
+            bool m = s + n <= T;
+            for (int i = 0; m && i < n; ++i) m = row[s + i] == pfx.ids[i];
+            unsigned long long mask = __ballot(m);
+            while (mask) {
+                const int b = __ffsll((long long)mask) - 1;
+                mask &= mask - 1;
+                const int start = base + b;
+                const int node = trie_walk(tv, row + start, T - start);
+                if (node >= 0) {
+                    out = node;
+                    break;
+                }
+            }
+        }
+    }
+    if (lane == 0) {
+        res[r] = out;
+        res[R + r] = out;
+    }
+}
+
+__global__ void state_advance_kernel(grx_state_words* st, int bump_count) {
+    if (bump_count) {
+        const int c = (st->first_match != GRX_NO_MATCH) ? 0 : st->count;
+        st->count = c + 1;
+    }
+    st->first_match = GRX_NO_MATCH;
+    st->calls += 1;
+}
+
+extern "C" size_t grx_workspace_bytes(int32_t R) {
+    if (R < 0) return 0;
+    return sizeof(int32_t) * 2 * (size_t)R + 256;
+}
+
+int grx_resolve_rows(const grx_trie* trie, grx_state* state, const grx_rows* rows, const grx_constraint* con,
+                     int32_t* res, hipStream_t stream) {
+    PrefixArg pfx;
+    memset(&pfx, 0, sizeof(pfx));
+    pfx.n = con->n_prefix < 0 ? -1 : con->n_prefix;
+    for (int i = 0; i < pfx.n; ++i) pfx.ids[i] = con->prefix_ids[i];
+    TrieView tv{trie->child_off, trie->child_tok};
+    const int R = rows->R;
+    if (R == 0) return GRX_OK;
+    if (con->mode == GRX_MODE_COUNT) {
+        const int threads = 128;
+        hipLaunchKernelGGL(resolve_count_kernel, dim3((R + threads - 1) / threads), dim3(threads), 0, stream, tv,
+                           state->dev, rows->input_ids, rows->ids_stride, R, rows->T, pfx, con->prefix_index, res);
+    } else {
+        const int threads = 256;  // 4 rows per workgroup
+        const int rows_per_block = threads / GRX_WAVE;
+        hipLaunchKernelGGL(resolve_fixed_kernel, dim3((R + rows_per_block - 1) / rows_per_block), dim3(threads), 0,
+                           stream, tv, rows->input_ids, rows->ids_stride, R, rows->T, pfx, con->eos_token_id, res);
+    }
+    GRX_CHECK_HIP(hipGetLastError());
+    return GRX_OK;
+}
+
+int grx_state_advance(grx_state* state, int bump_count, hipStream_t stream) {
+    if (!state) return GRX_OK;
+    hipLaunchKernelGGL(state_advance_kernel, dim3(1), dim3(1), 0, stream, state->dev, bump_count);
+    GRX_CHECK_HIP(hipGetLastError());
+    return GRX_OK;
+}
+
+int grx_check_step_args(const char* who, const grx_trie* trie, const grx_state* state, const grx_rows* rows,
+                        const grx_constraint* con, const void* workspace, size_t workspace_bytes) {
+    GRX_REQUIRE(trie && rows && con, GRX_E_INVALID, "%s: null trie/rows/constraint", who);
+    GRX_REQUIRE(rows->R >= 0 && rows->T >= 0 && rows->V >= 1, GRX_E_INVALID, "%s: bad shape R=%d T=%d V=%d", who,
+                rows->R, rows->T, rows->V);
+    GRX_REQUIRE(con->mode == GRX_MODE_COUNT || con->mode == GRX_MODE_FIXED_HINT, GRX_E_INVALID, "%s: bad mode %d", who,
+                con->mode);
+    GRX_REQUIRE(con->mode != GRX_MODE_COUNT || state != nullptr, GRX_E_INVALID,
+                "%s: the count-based mode needs a grx_state", who);
+    GRX_REQUIRE(con->n_prefix <= GRX_MAX_PREFIX, GRX_E_UNSUPPORTED, "%s: prefix_ids longer than %d tokens", who,
+                GRX_MAX_PREFIX);
+    GRX_REQUIRE(rows->dtype == GRX_F32 || rows->dtype == GRX_BF16 || rows->dtype == GRX_F16, GRX_E_INVALID,
+                "%s: bad dtype %d", who, rows->dtype);
+    if (rows->R > 0) {
+        GRX_REQUIRE(rows->scores != nullptr && (rows->T == 0 || rows->input_ids != nullptr), GRX_E_INVALID,
+                    "%s: null input_ids/scores", who);
+        GRX_REQUIRE(rows->ids_stride >= rows->T && rows->scores_stride >= rows->V, GRX_E_INVALID,
+                    "%s: row stride smaller than the row", who);
+        GRX_REQUIRE(workspace != nullptr && workspace_bytes >= grx_workspace_bytes(rows->R), GRX_E_WORKSPACE,
+                    "%s: workspace of %zu bytes is too small for %d rows (need %zu)", who, workspace_bytes, rows->R,
+                    grx_workspace_bytes(rows->R));
+        GRX_REQUIRE(((uintptr_t)workspace & 3u) == 0, GRX_E_INVALID, "%s: workspace must be 4-byte aligned", who);
+    }
+    GRX_REQUIRE(trie->max_token < rows->V, GRX_E_INVALID,
+                "%s: the trie holds token id %d but rows have only V=%d columns", who, trie->max_token, rows->V);
+    return GRX_OK;
+}

@@ -1,0 +1,328 @@
+"""Trie-constrained logits processors running on MI355X.
+
+Drop-in for the reference's ``ConstrainedLogitsProcessor``
+(reference: logit_processor.py:8-49), its seeded subclass
+(reference: analyze_rl_beam_hint.py:553-560) and -- in
+``fixed_hint_logit_processor.py`` of this package --
+``FixedHintConstrainedLogitsProcessor``.  Same constructor, attributes and
+``__call__(input_ids, scores) -> scores`` contract; the per-row Python loop,
+the nested-dict trie walk and the three dense tensor passes are replaced by two
+HIP kernels working on a CSR trie resident in HBM, and the shared ``count``
+lives on the device so that decode steps need no host round trip.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Callable, Optional
+
+import torch
+from transformers.generation import LogitsProcessor
+
+from . import _lib
+from .trie import FlatTrie, as_flat_trie
+
+_EMPTY_MSG = "No valid tokens for prefix_ids"
+_NOMATCH_MSG = "Failed to find a valid trie prefix match inside current sequence."
+
+
+def _eager_errors_default() -> bool:
+    return os.environ.get("GENREC_AMD_EAGER_ERRORS", "0") not in ("", "0", "false", "False")
+
+
+class _DeviceState:
+    """grx_state of one processor on one device."""
+
+    def __init__(self, device_index: int):
+        self.device_index = device_index
+        out = C.c_void_p()
+        with torch.cuda.device(device_index):
+            _lib.check(_lib.lib().grx_state_create(C.byref(out)))
+        self.ptr = out.value
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                _lib.lib().grx_state_destroy(self.ptr)
+        except Exception:
+            pass
+        self.ptr = None
+
+
+class _TrieConstrainedBase(LogitsProcessor):
+    """State and launch plumbing shared by the count-based and fixed-hint processors."""
+
+    _mode = _lib.GRX_MODE_COUNT
+
+    def __init__(
+        self,
+        prefix_allowed_tokens_fn: Callable[[list[int]], list[int]],
+        num_beams: int,
+        prefix_index: int = 3,
+        prefix_ids: Optional[list[int]] = None,
+        eos_token_id: Optional[int] = None,
+        *,
+        sync_errors: Optional[bool] = None,
+    ):
+        self._prefix_allowed_tokens_fn = prefix_allowed_tokens_fn
+        self._num_beams = num_beams
+        self.prefix_index = prefix_index
+        self.eos_token_id = eos_token_id
+        self.prefix_ids = prefix_ids
+        self.sync_errors = _eager_errors_default() if sync_errors is None else bool(sync_errors)
+        self._trie: Optional[FlatTrie] = None
+        self._states: dict[int, _DeviceState] = {}
+        self._workspaces: dict[tuple[int, int], torch.Tensor] = {}
+        self._active: Optional[int] = None  # device index of the last call
+
+    # -- trie ---------------------------------------------------------------------
+    @property
+    def trie(self) -> FlatTrie:
+        """CSR trie behind ``prefix_allowed_tokens_fn`` (built on first use)."""
+        if self._trie is None:
+            self._trie = as_flat_trie(self._prefix_allowed_tokens_fn)
+        return self._trie
+
+    # -- device plumbing --------------------------------------------------------------
+    def _state(self, index: int) -> _DeviceState:
+        st = self._states.get(index)
+        if st is None:
+            st = _DeviceState(index)
+            self._states[index] = st
+            self._on_new_state(st)
+        return st
+
+    def _on_new_state(self, st: _DeviceState) -> None:
+        pass
+
+    def _workspace(self, index: int, rows: int) -> torch.Tensor:
+        key = (index, rows)
+        ws = self._workspaces.get(key)
+        if ws is None:
+            nbytes = int(_lib.lib().grx_workspace_bytes(rows))
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=torch.device("cuda", index))
+            self._workspaces = {key: ws}  # keep only the latest shape
+        return ws
+
+    def _constraint(self) -> _lib.GrxConstraint:
+        con = _lib.GrxConstraint()
+        con.mode = self._mode
+        con.prefix_index = int(self.prefix_index)
+        if self.prefix_ids is None:
+            con.n_prefix = -1
+        else:
+            ids = [int(t) for t in self.prefix_ids]
+            if len(ids) > _lib.GRX_MAX_PREFIX:
+                raise _lib.GenrecHipError(f"prefix_ids longer than {_lib.GRX_MAX_PREFIX} tokens is not supported")
+            con.n_prefix = len(ids)
+            for i, t in enumerate(ids):
+                con.prefix_ids[i] = t
+        con.eos_token_id = -1 if self.eos_token_id is None else int(self.eos_token_id)
+        return con
+
+    def _rows(self, input_ids: torch.Tensor, scores: torch.Tensor) -> tuple[_lib.GrxRows, torch.Tensor, torch.Tensor]:
+        assert input_ids.dim() == 2, "input_ids must be a 2D tensor"
+        _lib.require_cuda(scores, "scores")
+        _lib.require_cuda(input_ids, "input_ids")
+        if scores.dim() != 2 or scores.shape[0] != input_ids.shape[0]:
+            raise ValueError(f"scores must be [rows, vocab] with rows == {input_ids.shape[0]}; got {tuple(scores.shape)}")
+        if input_ids.shape[0] % self._num_beams != 0:
+            # the reference fails on view(-1, num_beams, seq_len) (logit_processor.py:36)
+            raise RuntimeError(
+                f"shape '[-1, {self._num_beams}, {input_ids.shape[1]}]' is invalid for input of size {input_ids.numel()}"
+            )
+        if input_ids.dtype != torch.int64:
+            input_ids = input_ids.to(torch.int64)
+        if input_ids.shape[1] > 0 and input_ids.stride(1) != 1:
+            input_ids = input_ids.contiguous()
+        if scores.stride(1) != 1:
+            scores = scores.contiguous()
+        rows = _lib.GrxRows()
+        rows.input_ids = input_ids.data_ptr()
+        rows.ids_stride = input_ids.stride(0) if input_ids.shape[0] > 1 else max(input_ids.shape[1], 1)
+        rows.R = input_ids.shape[0]
+        rows.T = input_ids.shape[1]
+        rows.scores = scores.data_ptr()
+        rows.scores_stride = scores.stride(0) if scores.shape[0] > 1 else scores.shape[1]
+        rows.V = scores.shape[1]
+        rows.dtype = _lib.torch_dtype_code(scores.dtype)
+        return rows, input_ids, scores
+
+    def _device_index(self, t: torch.Tensor) -> int:
+        return t.device.index if t.device.index is not None else torch.cuda.current_device()
+
+    # -- the processor surface -----------------------------------------------------------
+    def __call__(self, input_ids: torch.LongTensor, scores: torch.FloatTensor) -> torch.FloatTensor:
+        rows, ids_keep, scores_keep = self._rows(input_ids, scores)
+        index = self._device_index(scores_keep)
+        out = torch.empty_like(scores_keep, memory_format=torch.contiguous_format)
+        with torch.cuda.device(index):
+            st = self._state(index)
+            ws = self._workspace(index, rows.R)
+            con = self._constraint()
+            _lib.check(
+                _lib.lib().grx_constrained_logsoftmax(
+                    self.trie.device_handle(scores_keep.device),
+                    st.ptr,
+                    C.byref(rows),
+                    C.byref(con),
+                    out.data_ptr(),
+                    out.stride(0) if out.shape[0] > 1 else out.shape[1],
+                    rows.dtype,
+                    ws.data_ptr(),
+                    ws.numel(),
+                    _lib.current_stream_ptr(scores_keep.device),
+                )
+            )
+        self._active = index
+        if self.sync_errors:
+            self.check_errors()
+        return out
+
+    def candidates(self, input_ids: torch.LongTensor, scores: torch.Tensor, cmax: Optional[int] = None):
+        """Fused form of ``__call__``: ``(count[R], token[R, cmax], logp[R, cmax])``.
+
+        ``token[r, :count[r]]`` are the allowed next tokens of row ``r``
+        (ascending) and ``logp`` their full-vocabulary log-probabilities in
+        fp32 -- the finite entries of what ``__call__`` would return.  Advances
+        ``count`` exactly like ``__call__``.
+        """
+        rows, ids_keep, scores_keep = self._rows(input_ids, scores)
+        index = self._device_index(scores_keep)
+        dev = scores_keep.device
+        if cmax is None:
+            cmax = max(self.trie.max_fanout, 1)
+        count = torch.empty(rows.R, dtype=torch.int32, device=dev)
+        tok = torch.empty((rows.R, cmax), dtype=torch.int32, device=dev)
+        logp = torch.empty((rows.R, cmax), dtype=torch.float32, device=dev)
+        self.candidates_into(input_ids, scores, count, tok, logp)
+        return count, tok, logp
+
+    def candidates_into(self, input_ids, scores, count: torch.Tensor, tok: torch.Tensor, logp: torch.Tensor) -> None:
+        """``candidates`` writing into caller-owned int32/int32/fp32 buffers (no allocation per step)."""
+        rows, ids_keep, scores_keep = self._rows(input_ids, scores)
+        index = self._device_index(scores_keep)
+        cmax = tok.shape[1]
+        assert tok.is_contiguous() and logp.is_contiguous() and count.is_contiguous()
+        assert tok.dtype == torch.int32 and count.dtype == torch.int32 and logp.dtype == torch.float32
+        assert tok.shape == logp.shape and tok.shape[0] == rows.R and count.shape[0] == rows.R
+        with torch.cuda.device(index):
+            st = self._state(index)
+            ws = self._workspace(index, rows.R)
+            con = self._constraint()
+            _lib.check(
+                _lib.lib().grx_constrained_candidates(
+                    self.trie.device_handle(scores_keep.device),
+                    st.ptr,
+                    C.byref(rows),
+                    C.byref(con),
+                    count.data_ptr(),
+                    tok.data_ptr(),
+                    logp.data_ptr(),
+                    cmax,
+                    ws.data_ptr(),
+                    ws.numel(),
+                    _lib.current_stream_ptr(scores_keep.device),
+                )
+            )
+        self._active = index
+        if self.sync_errors:
+            self.check_errors()
+
+    # -- errors ----------------------------------------------------------------------------
+    def _read_state(self, index: int) -> tuple[int, int, int, int]:
+        st = self._states.get(index)
+        if st is None:
+            return (0, 0, -1, 0)
+        buf = (C.c_int32 * 4)()
+        with torch.cuda.device(index):
+            _lib.check(
+                _lib.lib().grx_state_read(st.ptr, C.byref(buf), _lib.current_stream_ptr(torch.device("cuda", index)))
+            )
+        return (buf[0], buf[1], buf[2], buf[3])
+
+    def check_errors(self) -> None:
+        """Raise what the reference would have raised inside ``__call__``.
+
+        The kernels record the first (lowest-row) failure of a call on the
+        device; reading it back synchronises the stream.  Called after every
+        ``__call__`` when ``sync_errors`` is set (or ``GENREC_AMD_EAGER_ERRORS=1``),
+        otherwise from ``reset()`` and when ``count`` is read.
+        """
+        for index in list(self._states):
+            _, code, row, _ = self._read_state(index)
+            if code == _lib.GRX_ROWERR_NONE:
+                continue
+            with torch.cuda.device(index):
+                _lib.check(
+                    _lib.lib().grx_state_clear_error(
+                        self._states[index].ptr, _lib.current_stream_ptr(torch.device("cuda", index))
+                    )
+                )
+            if code == _lib.GRX_ROWERR_EMPTY:
+                raise AssertionError(_EMPTY_MSG)
+            if code == _lib.GRX_ROWERR_NOMATCH:
+                raise ValueError(f"{_NOMATCH_MSG} prefix_ids={self.prefix_ids}, row={row}")
+            raise _lib.GenrecHipError(f"row {row}: allowed-token set larger than the candidate buffer")
+
+
+class ConstrainedLogitsProcessor(_TrieConstrainedBase):
+    """Count-based window processor (reference: logit_processor.py:8-49).
+
+    ``count`` is one counter shared by all rows: row r's window is its last
+    ``prefix_index + count`` tokens, ``count`` advances once per call, and when
+    ``prefix_ids`` is given a row ending in exactly those tokens resets it
+    (logit_processor.py:39-41,48).  ``initial_count`` reproduces the seeded
+    variant whose counter starts at, and resets to, the number of hint tokens
+    already in the prompt (analyze_rl_beam_hint.py:553-560).
+    """
+
+    _mode = _lib.GRX_MODE_COUNT
+
+    def __init__(
+        self,
+        prefix_allowed_tokens_fn,
+        num_beams: int,
+        prefix_index: int = 3,
+        prefix_ids: Optional[list[int]] = None,
+        eos_token_id: Optional[int] = None,
+        *,
+        initial_count: int = 0,
+        sync_errors: Optional[bool] = None,
+    ):
+        super().__init__(
+            prefix_allowed_tokens_fn, num_beams, prefix_index, prefix_ids, eos_token_id, sync_errors=sync_errors
+        )
+        self.initial_count = int(initial_count)
+        self._count_host = self.initial_count  # value to push to a device on first use / after a set
+
+    def _on_new_state(self, st: _DeviceState) -> None:
+        self._push_count(st, self._count_host)
+
+    def _push_count(self, st: _DeviceState, value: int) -> None:
+        with torch.cuda.device(st.device_index):
+            _lib.check(
+                _lib.lib().grx_state_set_count(
+                    st.ptr, int(value), _lib.current_stream_ptr(torch.device("cuda", st.device_index))
+                )
+            )
+
+    @property
+    def count(self) -> int:
+        """The shared step counter.  Reading it synchronises with the device."""
+        if self._active is None or self._active not in self._states:
+            return self._count_host
+        self.check_errors()
+        return self._read_state(self._active)[0]
+
+    @count.setter
+    def count(self, value: int) -> None:
+        self._count_host = int(value)
+        for st in self._states.values():
+            self._push_count(st, self._count_host)
+
+    def reset(self) -> None:
+        if self._states:
+            self.check_errors()
+        self.count = self.initial_count

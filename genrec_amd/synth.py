@@ -1,0 +1,180 @@
+"""Synthetic workloads for tests and benchmarks: an offline SID tokenizer,
+synthetic index files, and decode-step inputs that follow real trie paths.
+
+No Qwen2.5 tokenizer is available offline, so ``SidTokenizer`` reproduces the
+only part of it the decoding path depends on: the assistant prefix
+``"<|im_start|>assistant\\n"`` -> ``[151644, 77091, 198]``, EOS 151645, and every
+``<x_n>`` SID token -> ``151665 + rank`` in the lexicographically sorted list of
+new tokens, which is what ``tokenizer.add_tokens(sorted(...))`` yields
+(reference: preprocess_data_sft_rl.py:80-89, evaluate.py:263-267).
+"""
+
+from __future__ import annotations
+
+import json
+import re
+from types import SimpleNamespace
+from typing import Iterable, Optional, Sequence
+
+import numpy as np
+
+ASSISTANT_PREFIX = "<|im_start|>assistant\n"
+ASSISTANT_PREFIX_IDS = [151644, 77091, 198]
+EOS_TOKEN_ID = 151645
+BASE_VOCAB = 151665  # len(tokenizer) of Qwen2.5 before SID tokens are added
+STOCK_EMBEDDING_ROWS = 151936  # embedding rows of stock Qwen2.5 (<= 3B) checkpoints
+
+_SID_RE = re.compile(r"<[a-z]_\d+>")
+
+
+def padded_vocab(n_tokens: int, multiple: int = 64, current: int = STOCK_EMBEDDING_ROWS) -> int:
+    """Logit width after the embedding resize (reference:
+    src/llamafactory/model/model_utils/embedding.py:181-188): unchanged while the
+    tokenizer fits the checkpoint, else padded up to a multiple of 64."""
+    if n_tokens <= current:
+        return current
+    return ((n_tokens + multiple - 1) // multiple) * multiple
+
+
+class SidTokenizer:
+    """Offline stand-in for the Qwen2.5 tokenizer restricted to SID text."""
+
+    eos_token_id = EOS_TOKEN_ID
+    pad_token_id = 151643
+
+    def __init__(self, new_tokens: Iterable[str]):
+        self.new_tokens = sorted(set(new_tokens))
+        self._id = {tok: BASE_VOCAB + i for i, tok in enumerate(self.new_tokens)}
+        self._tok = {i: t for t, i in self._id.items()}
+
+    @classmethod
+    def from_index(cls, index_path: str) -> "SidTokenizer":
+        with open(index_path, encoding="utf-8") as f:
+            data = json.load(f)
+        toks = set()
+        for raw in data.values():
+            toks.update(raw if isinstance(raw, list) else [raw])
+        return cls(toks)
+
+    def __len__(self) -> int:
+        return BASE_VOCAB + len(self.new_tokens)
+
+    @property
+    def vocab_size_padded(self) -> int:
+        return padded_vocab(len(self))
+
+    def encode(self, text: str) -> list[int]:
+        ids: list[int] = []
+        pos = 0
+        while pos < len(text):
+            if text.startswith(ASSISTANT_PREFIX, pos):
+                ids.extend(ASSISTANT_PREFIX_IDS)
+                pos += len(ASSISTANT_PREFIX)
+                continue
+            m = _SID_RE.match(text, pos)
+            if not m or m.group(0) not in self._id:
+                raise ValueError(f"SidTokenizer cannot encode {text[pos:pos + 24]!r}")
+            ids.append(self._id[m.group(0)])
+            pos = m.end()
+        return ids
+
+    def __call__(self, text: str, add_special_tokens: bool = False):
+        return SimpleNamespace(input_ids=self.encode(text))
+
+    def decode(self, ids: Sequence[int], skip_special_tokens: bool = True) -> str:
+        return "".join(self._tok.get(int(i), "") for i in ids)
+
+    def apply_chat_template(self, messages, add_generation_prompt: bool = False, tokenize: bool = False) -> str:
+        body = "".join(f"<|im_start|>{m['role']}\n{m['content']}<|im_end|>\n" for m in messages)
+        return body + (ASSISTANT_PREFIX if add_generation_prompt else "")
+
+    def code_table(self, n_rows: Optional[int] = None) -> np.ndarray:
+        """int32 table token id -> the integer after '_' (-1 for non-SID tokens):
+        what ``re.findall(r"_(\\d+)", text)`` extracts (reference: util.py:133-134)."""
+        n = n_rows if n_rows is not None else len(self)
+        table = np.full(n, -1, dtype=np.int32)
+        for tok, i in self._id.items():
+            table[i] = int(tok[tok.index("_") + 1 : -1])
+        return table
+
+
+def synthetic_index(n_items: int, levels: int, codebook: int, seed: int = 0) -> dict[str, list[str]]:
+    """Random SID index in the ``{item_id: ["<a_x>", "<b_y>", ...]}`` format of
+    ``*.index.json`` (reference: index/generate_indices.py:77-92); duplicates
+    are allowed, as in real files."""
+    rng = np.random.default_rng(seed)
+    letters = "abcdefghij"[:levels]
+    codes = rng.integers(0, codebook, size=(n_items, levels))
+    return {str(i): [f"<{letters[l]}_{int(codes[i, l])}>" for l in range(levels)] for i in range(n_items)}
+
+
+def write_index(path: str, index: dict) -> str:
+    with open(path, "w", encoding="utf-8") as f:
+        json.dump(index, f)
+    return path
+
+
+def sample_decode_rows(
+    trie,
+    n_groups: int,
+    num_beams: int,
+    step: int,
+    prompt_len: int = 61,
+    prefix_ids: Sequence[int] = ASSISTANT_PREFIX_IDS,
+    seed: int = 0,
+    hint_depths: Optional[Sequence[int]] = None,
+    distractors: bool = False,
+) -> np.ndarray:
+    """``input_ids`` of one decode step: int64 [n_groups * num_beams, T].
+
+    Every row is ``prompt_len`` random ordinary tokens, the assistant prefix,
+    an optional hint (a valid trie path of ``hint_depths[g]`` tokens, same for
+    the whole group, left-padded so that all rows have equal length) and then
+    ``step`` generated tokens chosen uniformly among the trie children, so the
+    allowed-set sizes follow the real fan-out.  With ``distractors`` a second,
+    invalid occurrence of the prefix is planted in the prompt.
+    """
+    rng = np.random.default_rng(seed)
+    n_pre = len(prefix_ids)
+    max_hint = max(hint_depths) if hint_depths is not None else 0
+    T = prompt_len + max_hint + n_pre + step
+    root = trie.node_of(list(prefix_ids))
+    if root < 0:
+        raise ValueError("prefix_ids is not a path of the trie")
+    rows = np.empty((n_groups * num_beams, T), dtype=np.int64)
+    pad = SidTokenizer.pad_token_id
+
+    for g in range(n_groups):
+        depth = int(hint_depths[g]) if hint_depths is not None else 0
+        prompt = rng.integers(0, 151643, size=prompt_len).tolist()
+        if distractors and prompt_len >= n_pre + 2:
+            at = int(rng.integers(0, prompt_len - n_pre - 1))
+            prompt[at : at + n_pre] = list(prefix_ids)
+            prompt[at + n_pre] = 7  # not a trie token: this occurrence has no continuation
+        hint_full: list[int] = []
+        node = root
+        for _ in range(depth):
+            kids = trie.children(node)
+            tok = int(kids[rng.integers(0, len(kids))])
+            hint_full.append(tok)
+            node = _child(trie, node, tok)
+        head = [pad] * (max_hint - depth) + prompt + list(prefix_ids) + hint_full
+        for k in range(num_beams):
+            cur = node
+            gen = []
+            for _ in range(step):
+                kids = trie.children(cur)
+                if not kids:
+                    raise ValueError("requested step is deeper than the trie")
+                tok = int(kids[rng.integers(0, len(kids))])
+                gen.append(tok)
+                cur = _child(trie, cur, tok)
+            rows[g * num_beams + k] = head + gen
+    return rows
+
+
+def _child(trie, node: int, tok: int) -> int:
+    lo, hi = int(trie.child_off[node]), int(trie.child_off[node + 1])
+    pos = lo + int(np.searchsorted(trie.child_tok[lo:hi], tok))
+    assert pos < hi and int(trie.child_tok[pos]) == tok
+    return pos + 1

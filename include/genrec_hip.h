@@ -1,0 +1,266 @@
+/*
+ * genrec_hip.h -- C ABI of libgenrec_hip.so: trie-constrained semantic-ID (SID)
+ * decoding for MI355X (gfx950).
+ *
+ * Every entry point takes plain pointers and sizes.  Pointers documented as
+ * "device" must be HIP device memory on the device that is current when the
+ * call is made; "host" pointers are ordinary memory.  All functions return
+ * GRX_OK (0) on success or a negative GRX_E_* code; grx_last_error() gives a
+ * message for the calling thread's last failure.  Kernels are enqueued on the
+ * caller's stream (hipStream_t passed as void*) and never synchronise unless
+ * the function says so.
+ *
+ * Each declaration cites the reference code (WncFht/GenRec, paths relative to
+ * the reference checkout) whose behaviour it replaces.
+ */
+#ifndef GENREC_HIP_H
+#define GENREC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GRX_ABI_VERSION 1
+
+#if defined(GRX_BUILDING)
+#define GRX_API __attribute__((visibility("default")))
+#else
+#define GRX_API
+#endif
+
+/* status codes */
+#define GRX_OK 0
+#define GRX_E_INVALID (-1)     /* bad argument (null pointer, negative size, ...) */
+#define GRX_E_HIP (-2)         /* a HIP runtime call failed                         */
+#define GRX_E_UNSUPPORTED (-3) /* argument outside what the kernels handle          */
+#define GRX_E_WORKSPACE (-4)   /* workspace too small                               */
+
+/* element types of logit rows */
+#define GRX_F32 0
+#define GRX_BF16 1
+#define GRX_F16 2
+
+/* how the allowed-token set of a row is resolved */
+#define GRX_MODE_COUNT 0      /* logit_processor.py:29-49 (count-based window)      */
+#define GRX_MODE_FIXED_HINT 1 /* fixed_hint_logit_processor.py:18-61 (prefix scan)  */
+
+/* per-row resolution failures, reported through grx_state (lowest row wins) */
+#define GRX_ROWERR_NONE 0
+#define GRX_ROWERR_EMPTY 1   /* AssertionError "No valid tokens for prefix_ids"
+                                (logit_processor.py:43-44,
+                                 fixed_hint_logit_processor.py:59-60)               */
+#define GRX_ROWERR_NOMATCH 2 /* ValueError "Failed to find a valid trie prefix
+                                match" (fixed_hint_logit_processor.py:37-40)        */
+#define GRX_ROWERR_OVERFLOW 3 /* allowed set larger than the compact buffer (cmax)  */
+
+#define GRX_MAX_PREFIX 16 /* longest assistant-prefix token list accepted           */
+
+typedef struct grx_trie grx_trie;   /* flat CSR child table resident in HBM         */
+typedef struct grx_state grx_state; /* device-resident processor state words        */
+
+GRX_API int grx_abi_version(void);
+GRX_API const char* grx_last_error(void);
+
+/* ------------------------------------------------------------------ trie --- */
+
+/*
+ * Upload a prefix trie as a CSR child table.  Replaces the nested-dict
+ * llamafactory.extras.trie.Trie (src/llamafactory/extras/trie.py:18-97).
+ *
+ * Node 0 is the root.  The children of node n are the edges
+ * child_off[n] .. child_off[n+1]-1; child_tok[e] is the token on edge e and
+ * is strictly increasing inside one node; the node reached through edge e has
+ * id e + 1 (so n_nodes == n_edges + 1).  child_off has n_nodes + 1 entries.
+ * Host pointers; the arrays are copied.  Synchronous.
+ */
+GRX_API int grx_trie_create(const int32_t* child_off, const int32_t* child_tok, int32_t n_nodes, int32_t n_edges,
+                    grx_trie** out);
+GRX_API int grx_trie_destroy(grx_trie* trie);
+/* largest number of children of any node (upper bound for cmax below) */
+GRX_API int32_t grx_trie_max_fanout(const grx_trie* trie);
+/* largest token id on any edge (-1 for an empty trie) */
+GRX_API int32_t grx_trie_max_token(const grx_trie* trie);
+
+/* ----------------------------------------------------------------- state --- */
+
+/*
+ * Device-resident words that carry what ConstrainedLogitsProcessor keeps in
+ * Python attributes: the shared step counter `count`
+ * (logit_processor.py:24,27,40,48) and the first per-row failure of a call.
+ * Keeping them on the device lets consecutive decode steps run without a
+ * host round trip.  grx_state_create/destroy/read synchronise; the setters
+ * are enqueued on `stream`.
+ */
+GRX_API int grx_state_create(grx_state** out);
+GRX_API int grx_state_destroy(grx_state* st);
+GRX_API int grx_state_set_count(grx_state* st, int32_t count, void* stream);
+GRX_API int grx_state_clear_error(grx_state* st, void* stream);
+/* out[0]=count, out[1]=row error code (GRX_ROWERR_*), out[2]=row index of it, out[3]=calls so far */
+GRX_API int grx_state_read(grx_state* st, int32_t out[4], void* stream);
+
+/* ------------------------------------------------- constrained log-softmax --- */
+
+typedef struct grx_rows {
+    const int64_t* input_ids; /* device [R, T], row stride ids_stride (elements)   */
+    int64_t ids_stride;
+    int32_t R;                /* rows = batch * beams                               */
+    int32_t T;                /* tokens per row so far                              */
+    const void* scores;       /* device [R, V] logits, row stride scores_stride     */
+    int64_t scores_stride;    /* elements                                           */
+    int32_t V;
+    int32_t dtype;            /* GRX_F32 / GRX_BF16 / GRX_F16                       */
+} grx_rows;
+
+typedef struct grx_constraint {
+    int32_t mode;             /* GRX_MODE_*                                         */
+    int32_t prefix_index;     /* logit_processor.py:15                              */
+    int32_t n_prefix;         /* -1: prefix_ids is None; else length (<= GRX_MAX_PREFIX) */
+    int32_t eos_token_id;     /* -1: None                                           */
+    int64_t prefix_ids[GRX_MAX_PREFIX];
+} grx_constraint;
+
+/* bytes of device scratch the two calls below need for R rows */
+GRX_API size_t grx_workspace_bytes(int32_t R);
+
+/*
+ * Processor surface.  out[r, v] = log_softmax(scores[r, :])[v] for the tokens
+ * v the trie allows after row r, -inf elsewhere; `count` advances by one.
+ * Replaces ConstrainedLogitsProcessor.__call__ (logit_processor.py:29-49) and
+ * FixedHintConstrainedLogitsProcessor.__call__
+ * (fixed_hint_logit_processor.py:79-96).  `out` is device [R, V] with row
+ * stride out_stride and element type out_dtype; it must not alias `scores`.
+ * `state` may be NULL in GRX_MODE_FIXED_HINT only if errors need not be
+ * reported.
+ */
+GRX_API int grx_constrained_logsoftmax(const grx_trie* trie, grx_state* state, const grx_rows* rows,
+                               const grx_constraint* con, void* out, int64_t out_stride, int32_t out_dtype,
+                               void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * Fused form of the same step: instead of the dense [R, V] result it emits,
+ * per row, the allowed tokens and their log-probabilities --
+ * cand_count[r] <= cmax, cand_tok[r, i] ascending, cand_logp[r, i] (fp32) --
+ * which is everything the beam step below consumes.  Reads every logit once
+ * and writes O(R * cmax).
+ */
+GRX_API int grx_constrained_candidates(const grx_trie* trie, grx_state* state, const grx_rows* rows,
+                               const grx_constraint* con, int32_t* cand_count, int32_t* cand_tok,
+                               float* cand_logp, int32_t cmax, void* workspace, size_t workspace_bytes,
+                               void* stream);
+
+/* -------------------------------------------------------------- beam step --- */
+
+/*
+ * One iteration of beam search over the compact candidates: the arithmetic of
+ * transformers.GenerationMixin._beam_search steps b-g
+ * (generation/utils.py:3418-3502 of transformers 5.15.0: accumulate, top-2K,
+ * parent/token split, stopping criteria, running top-K, finished merge,
+ * early-stop heuristic), called by the reference from evaluate.py:363-371 and
+ * MIMIGenRec.py:79.  One workgroup per prompt group.  Ties are broken by
+ * (score descending, beam*V+token ascending).
+ *
+ * All pointers are device memory.  *_in and *_out must be different buffers.
+ * B groups of K beams; n_keep = max(2, 1 + n_eos) * K candidates are kept.
+ */
+typedef struct grx_beam_step_args {
+    int32_t B, K, V, n_keep;
+    int32_t cmax;
+    int32_t cur_len;        /* tokens per running sequence before this step        */
+    int32_t prompt_len;     /* decoder_prompt_len                                   */
+    int32_t max_length;     /* row length of the sequence buffers                   */
+    int32_t copy_from;      /* first position of a sequence row that must be
+                               copied when beams are re-ordered (0 = whole row;
+                               prompt_len when all beams of a group share the
+                               prompt and the out buffers already hold it)         */
+    int32_t eos_token_id;   /* -1: none                                             */
+    int32_t early_stopping; /* 0 False, 1 True, 2 "never"                           */
+    float length_penalty;
+    const int32_t* cand_count; /* [B*K]                                             */
+    const int32_t* cand_tok;   /* [B*K, cmax]                                       */
+    const float* cand_logp;    /* [B*K, cmax]                                       */
+    /* running beams */
+    const int64_t* run_seq_in;  int64_t* run_seq_out;      /* [B, K, max_length]     */
+    const float* run_score_in;  float* run_score_out;      /* [B, K]                 */
+    const int32_t* run_bidx_in; int32_t* run_bidx_out;     /* [B, K, max_length - prompt_len] */
+    /* finished beams */
+    const int64_t* fin_seq_in;  int64_t* fin_seq_out;      /* [B, K, max_length]     */
+    const float* fin_score_in;  float* fin_score_out;      /* [B, K]                 */
+    const int32_t* fin_bidx_in; int32_t* fin_bidx_out;     /* [B, K, max_length - prompt_len] */
+    const uint8_t* fin_done_in; uint8_t* fin_done_out;     /* [B, K] is_sent_finished */
+    uint8_t* unsat;            /* [B] is_early_stop_heuristic_unsatisfied, in/out   */
+    /* per-step results (may be NULL) */
+    float* topk_score;         /* [B, n_keep]                                       */
+    int32_t* topk_parent;      /* [B, n_keep] beam index inside the group           */
+    int32_t* topk_token;       /* [B, n_keep]                                       */
+    uint8_t* topk_hit;         /* [B, n_keep] next_token_hits_stopping_criteria     */
+    int32_t* next_parent;      /* [B*K] flat cache-reorder index (b*K + parent)     */
+} grx_beam_step_args;
+
+GRX_API int grx_beam_step(const grx_beam_step_args* args, void* stream);
+
+/* ----------------------------------------------------------------- scoring --- */
+
+/*
+ * Rule / prefix / NDCG rewards on SID code tuples (the integers the reference
+ * extracts with re.findall(r"_(\d+)") -- util.py:133-134).  Replaces
+ * rule_reward, prefix_rule_reward and ndcg_rule_reward
+ * (rewards/ranking_reward.py:42-110).  pred [R, Lp] and gt [R, Lg] are device
+ * int32 code rows with per-row lengths pred_len / gt_len (number of codes
+ * parsed from the text; rows are padded to Lp / Lg).  Any of the three
+ * outputs may be NULL.  ndcg_weights is device fp32 [K]
+ * (-1/log2(i+2) normalised to sum -1, computed by the caller in float64 as
+ * ranking_reward.py:83-84 does).  R must be a multiple of K for the NDCG
+ * reward; rows beyond the last full group get no NDCG value, as in the
+ * reference loop (ranking_reward.py:101-107).
+ */
+GRX_API int grx_sid_rewards(const int32_t* pred, const int32_t* pred_len, int32_t Lp, const int32_t* gt,
+                    const int32_t* gt_len, int32_t Lg, int32_t R, int32_t K, int32_t prefix_normalize,
+                    const float* ndcg_weights, float* rule_out, float* prefix_out, float* ndcg_out,
+                    void* stream);
+
+/*
+ * HR@k / NDCG@k support: rank of the first beam equal to the target
+ * (evaluate.py:162-166).  beams [n, n_beam, L] and target [n, L] are device
+ * int32 code rows (a beam equals the target when all L codes match).
+ * first_hit [n] receives the rank, or n_beam when no beam matches (may be
+ * NULL); rank_hist [n_beam + 1] (device int32, zeroed by the caller) counts
+ * the samples per rank.  HR@k and NDCG@k (evaluate.py:168-180) follow from the
+ * histogram on the host in float64.
+ */
+GRX_API int grx_hit_ranks(const int32_t* beams, const int32_t* target, int32_t n, int32_t n_beam, int32_t L,
+                  int32_t* first_hit, int32_t* rank_hist, void* stream);
+
+/*
+ * Per-group advantage: rewards[r] = nansum_f(rewards_per_func[r, f] *
+ * weights[f]); adv = (reward - mean_g) / (std_g + eps) with the unbiased std
+ * of each group of K consecutive rows (scale 1 "group"), the unbiased std of
+ * all R rows (scale 2 "batch") or no division (scale 0 "none").  Replaces
+ * fixed_hint_grpo_trainer.py:383-401 and
+ * TokenPrefixGRPOTrainer._group_normalize
+ * (token_prefix_grpo_trainer.py:41-45).  rewards_per_func is device fp32
+ * [R, n_funcs] (after the all-gather), weights device fp32 [n_funcs].
+ * Outputs (device fp32 [R], any may be NULL): rewards, advantages,
+ * group_mean, group_std.
+ */
+GRX_API int grx_group_advantage(const float* rewards_per_func, const float* weights, int32_t R, int32_t n_funcs,
+                        int32_t K, int32_t scale, float eps, float* rewards, float* advantages,
+                        float* group_mean, float* group_std, void* stream);
+
+/*
+ * Token-wise masked group normalisation
+ * (TokenPrefixGRPOTrainer._group_normalize_tokenwise,
+ * token_prefix_grpo_trainer.py:47-63): for every group of K rows and token
+ * position t, mean/var over the rows with mask 1 (biased variance, denominator
+ * clamped to 1), out = (v - mean) / sqrt(var + eps) * mask.  values / mask /
+ * out are device fp32 [R, Tc].
+ */
+GRX_API int grx_group_normalize_tokenwise(const float* values, const float* mask, int32_t R, int32_t Tc, int32_t K,
+                                  float eps, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GENREC_HIP_H */
