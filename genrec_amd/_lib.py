@@ -36,6 +36,8 @@ EXPORTED_SYMBOLS = (
     "grx_workspace_bytes",
     "grx_constrained_logsoftmax",
     "grx_constrained_candidates",
+    "grx_timing_enable",
+    "grx_timing_read",
     "grx_beam_step",
     "grx_sid_rewards",
     "grx_hit_ranks",
@@ -149,6 +151,10 @@ def _declare(lib: C.CDLL) -> None:
     lib.grx_constrained_candidates.argtypes = [
         vp, vp, C.POINTER(GrxRows), C.POINTER(GrxConstraint), vp, vp, vp, i32, vp, C.c_size_t, vp,
     ]
+    lib.grx_timing_enable.restype = C.c_int
+    lib.grx_timing_enable.argtypes = [C.c_int]
+    lib.grx_timing_read.restype = C.c_int
+    lib.grx_timing_read.argtypes = [C.POINTER(C.c_double), C.POINTER(i32)]
     lib.grx_beam_step.restype = C.c_int
     lib.grx_beam_step.argtypes = [C.POINTER(GrxBeamStepArgs), vp]
     lib.grx_sid_rewards.restype = C.c_int

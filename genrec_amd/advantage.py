@@ -1,0 +1,108 @@
+"""Group-relative advantages of a GRPO rollout shard.
+
+Mirror of the reward aggregation the reference trainers run after scoring
+(fixed_hint_grpo_trainer.py:382-408; TokenPrefixGRPOTrainer._group_normalize,
+_group_normalize_tokenwise and _build_ndcg_rank_penalties,
+token_prefix_grpo_trainer.py:41-63,151-161): gather the per-function rewards of
+all ranks, weight and nansum them, normalise inside each group of
+``num_generations`` consecutive rows, and keep the local slice.
+
+Prompt groups never straddle ranks, so decoding needs no communication; the one
+exchange is this all-gather of a few KB per rank, issued through
+``torch.distributed`` (backend "nccl" is RCCL on ROCm: one hop over xGMI).
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+from . import _lib
+
+_SCALE = {"none": 0, "group": 1, "batch": 2}
+
+
+def gather_rows(t: torch.Tensor) -> torch.Tensor:
+    """All-gather along dim 0 (``accelerate.utils.gather``); identity without a process group."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return t
+    t = t.contiguous()
+    out = torch.empty((dist.get_world_size() * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(out, t)
+    return out
+
+
+def _dev_index(t: torch.Tensor) -> int:
+    return t.device.index if t.device.index is not None else torch.cuda.current_device()
+
+
+def group_advantages(rewards_per_func: torch.Tensor, reward_weights: torch.Tensor, num_generations: int,
+                     scale_rewards: str = "group", eps: float = 1e-4):
+    """(rewards, advantages, group_mean, std) for [R, n_funcs] fp32 rewards on the device
+    (reference: fixed_hint_grpo_trainer.py:383-401)."""
+    if scale_rewards not in _SCALE:
+        raise ValueError(
+            f"Invalid value for scale_rewards: {scale_rewards}. Must be one of 'batch', 'group', or 'none'."
+        )
+    _lib.require_cuda(rewards_per_func, "rewards_per_func")
+    rpf = rewards_per_func.to(torch.float32).contiguous()
+    w = reward_weights.to(device=rpf.device, dtype=torch.float32).contiguous()
+    R, n_funcs = rpf.shape
+    outs = [torch.empty(R, dtype=torch.float32, device=rpf.device) for _ in range(4)]
+    with torch.cuda.device(_dev_index(rpf)):
+        _lib.check(
+            _lib.lib().grx_group_advantage(rpf.data_ptr(), w.data_ptr(), R, n_funcs, int(num_generations),
+                                           _SCALE[scale_rewards], float(eps), outs[0].data_ptr(), outs[1].data_ptr(),
+                                           outs[2].data_ptr(), outs[3].data_ptr(), _lib.current_stream_ptr(rpf.device))
+        )
+    return tuple(outs)
+
+
+def group_normalize(values: torch.Tensor, group_size: int, eps: float = 1e-4) -> torch.Tensor:
+    """``(v - mean_g) / (std_g + eps)`` with the unbiased group std
+    (reference: token_prefix_grpo_trainer.py:41-45)."""
+    ones = torch.ones(1, dtype=torch.float32, device=values.device)
+    return group_advantages(values.reshape(-1, 1), ones, group_size, "group", eps)[1]
+
+
+def group_normalize_tokenwise(values: torch.Tensor, mask: torch.Tensor, group_size: int, eps: float = 1e-4
+                              ) -> torch.Tensor:
+    """Mask-aware per-position group normalisation (reference: token_prefix_grpo_trainer.py:47-63)."""
+    _lib.require_cuda(values, "values")
+    v = values.to(torch.float32).contiguous()
+    m = mask.to(device=v.device, dtype=torch.float32).contiguous()
+    R, Tc = v.shape
+    out = torch.empty_like(v)
+    with torch.cuda.device(_dev_index(v)):
+        _lib.check(
+            _lib.lib().grx_group_normalize_tokenwise(v.data_ptr(), m.data_ptr(), R, Tc, int(group_size), float(eps),
+                                                     out.data_ptr(), _lib.current_stream_ptr(v.device))
+        )
+    return out
+
+
+def ndcg_rank_penalties(batch_size: int, num_generations: int, device, process_index: int = 0) -> torch.Tensor:
+    """Per-row rank penalties of the token-level trainer (reference: token_prefix_grpo_trainer.py:151-161)."""
+    w = torch.tensor([-1.0 / math.log2(i + 2) for i in range(num_generations)], dtype=torch.float32, device=device)
+    w = -w / w.sum()
+    idx = (torch.arange(batch_size, device=device) + process_index * batch_size) % num_generations
+    return w[idx]
+
+
+def rollout_advantages(local_rewards_per_func: torch.Tensor, reward_weights: torch.Tensor, num_generations: int,
+                       scale_rewards: str = "group", process_index: Optional[int] = None):
+    """The whole exchange step of a rollout shard: all-gather the local
+    ``[R_local, n_funcs]`` rewards, normalise per group, return
+    ``(local_advantages, all_advantages, rewards, group_mean, std)``
+    (reference: fixed_hint_grpo_trainer.py:382-408)."""
+    gathered = gather_rows(local_rewards_per_func)
+    rewards, adv, mean, std = group_advantages(gathered, reward_weights, num_generations, scale_rewards)
+    if process_index is None:
+        process_index = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+    n_local = local_rewards_per_func.shape[0]
+    local = adv[process_index * n_local : (process_index + 1) * n_local]
+    return local, adv, rewards, mean, std

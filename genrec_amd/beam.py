@@ -1,0 +1,231 @@
+"""Beam search over compact trie candidates on MI355X.
+
+The reference lets ``transformers`` run beam search (``model.generate(num_beams=K)``
+from evaluate.py:363-371, MIMIGenRec.py:79, analyze_rl_beam_hint.py:609-623), which
+adds the running scores to a dense [R, V] tensor and takes ``topk`` over
+[B, K*V].  Here the processor emits only the allowed tokens of each row, and
+one kernel (``grx_beam_step``) performs the whole iteration for a prompt group:
+accumulate, top-2K, parent/token split, stopping criteria, running top-K,
+finished-beam merge, sequence / parent gathers and the early-stop heuristic --
+the arithmetic of ``GenerationMixin._beam_search`` (transformers 5.15.0,
+generation/utils.py:3418-3502), with ties ordered by (score desc, beam*V+token asc).
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Callable, Optional
+
+import torch
+
+from . import _lib
+
+NEG = -1.0e9
+
+
+@dataclass
+class BeamStepResult:
+    topk_scores: torch.Tensor   # [B, n_keep] fp32
+    topk_parent: torch.Tensor   # [B, n_keep] int32, beam inside the group
+    topk_token: torch.Tensor    # [B, n_keep] int32
+    topk_hit: torch.Tensor      # [B, n_keep] uint8
+    next_parent: torch.Tensor   # [B*K] int32 flat KV-cache reorder index
+
+
+class BeamSearchState:
+    """Device-resident beam state, laid out like the loop variables of HF's
+    ``_beam_search`` (utils.py:3316-3351) and double-buffered so that a step
+    reads one copy and writes the other."""
+
+    def __init__(self, input_ids: torch.Tensor, num_beams: int, max_length: int, eos_token_id: Optional[int],
+                 pad_token_id: Optional[int] = None, length_penalty: float = 1.0, early_stopping=False,
+                 shared_prompt: bool = True):
+        _lib.require_cuda(input_ids, "input_ids")
+        R, cur_len = input_ids.shape
+        if R % num_beams:
+            raise ValueError(f"{R} rows do not split into groups of {num_beams} beams")
+        if max_length <= cur_len:
+            raise ValueError("max_length must exceed the prompt length")
+        dev = input_ids.device
+        self.device = dev
+        self.K = num_beams
+        self.B = R // num_beams
+        self.max_length = int(max_length)
+        self.eos = eos_token_id
+        self.length_penalty = float(length_penalty)
+        self.early_stopping = early_stopping
+        self.prompt_len = cur_len
+        self.cur_len = cur_len
+        self.n_keep = max(2, 1 + (1 if eos_token_id is not None else 0)) * num_beams
+        # when every beam of a group starts from the same prompt, re-ordering beams never changes
+        # positions < prompt_len, so the kernel only moves the generated suffix
+        self.copy_from = cur_len if shared_prompt else 0
+        fill = (pad_token_id or eos_token_id) if eos_token_id is not None else -1
+        B, K = self.B, self.K
+
+        def both(t):
+            return [t, t.clone()]
+
+        run_seq = torch.full((B, K, self.max_length), fill, dtype=torch.int64, device=dev)
+        run_seq[:, :, :cur_len] = input_ids.view(B, K, cur_len)
+        self.run_seq = both(run_seq)
+        self.fin_seq = both(run_seq.clone())
+        run_score = torch.zeros((B, K), dtype=torch.float32, device=dev)
+        run_score[:, 1:] = NEG
+        self.run_score = both(run_score)
+        self.fin_score = both(torch.full((B, K), NEG, dtype=torch.float32, device=dev))
+        lg = self.max_length - cur_len
+        self.run_bidx = both(torch.full((B, K, lg), -1, dtype=torch.int32, device=dev))
+        self.fin_bidx = both(torch.full((B, K, lg), -1, dtype=torch.int32, device=dev))
+        self.fin_done = both(torch.zeros((B, K), dtype=torch.uint8, device=dev))
+        self.unsat = torch.ones(B, dtype=torch.uint8, device=dev)
+        self.cur = 0  # index of the buffer that holds the current state
+        self._step_out = None
+
+    # -- views of the current state -------------------------------------------------
+    @property
+    def running_sequences(self) -> torch.Tensor:
+        return self.run_seq[self.cur]
+
+    @property
+    def running_beam_scores(self) -> torch.Tensor:
+        return self.run_score[self.cur]
+
+    @property
+    def sequences(self) -> torch.Tensor:
+        return self.fin_seq[self.cur]
+
+    @property
+    def beam_scores(self) -> torch.Tensor:
+        return self.fin_score[self.cur]
+
+    @property
+    def beam_indices(self) -> torch.Tensor:
+        return self.fin_bidx[self.cur]
+
+    @property
+    def is_sent_finished(self) -> torch.Tensor:
+        return self.fin_done[self.cur].bool()
+
+    def flat_running_sequences(self) -> torch.Tensor:
+        """[B*K, cur_len] view (row stride max_length) to hand to the processor."""
+        return self.run_seq[self.cur].view(self.B * self.K, self.max_length)[:, : self.cur_len]
+
+    def _outputs(self) -> BeamStepResult:
+        if self._step_out is None:
+            B, n, dev = self.B, self.n_keep, self.device
+            self._step_out = BeamStepResult(
+                torch.empty((B, n), dtype=torch.float32, device=dev),
+                torch.empty((B, n), dtype=torch.int32, device=dev),
+                torch.empty((B, n), dtype=torch.int32, device=dev),
+                torch.empty((B, n), dtype=torch.uint8, device=dev),
+                torch.empty(B * self.K, dtype=torch.int32, device=dev),
+            )
+        return self._step_out
+
+    def step(self, cand_count: torch.Tensor, cand_tok: torch.Tensor, cand_logp: torch.Tensor, vocab_size: int
+             ) -> BeamStepResult:
+        """Advance by one token from the processor's compact candidates."""
+        a = _lib.GrxBeamStepArgs()
+        i, o = self.cur, 1 - self.cur
+        out = self._outputs()
+        a.B, a.K, a.V, a.n_keep = self.B, self.K, int(vocab_size), self.n_keep
+        a.cmax = cand_tok.shape[1]
+        a.cur_len, a.prompt_len, a.max_length = self.cur_len, self.prompt_len, self.max_length
+        a.copy_from = self.copy_from
+        a.eos_token_id = -1 if self.eos is None else int(self.eos)
+        a.early_stopping = 1 if self.early_stopping is True else (2 if self.early_stopping == "never" else 0)
+        a.length_penalty = self.length_penalty
+        assert cand_count.dtype == torch.int32 and cand_tok.dtype == torch.int32 and cand_logp.dtype == torch.float32
+        assert cand_tok.is_contiguous() and cand_logp.is_contiguous() and cand_count.is_contiguous()
+        assert cand_count.shape[0] == self.B * self.K and cand_tok.shape == cand_logp.shape
+        a.cand_count, a.cand_tok, a.cand_logp = cand_count.data_ptr(), cand_tok.data_ptr(), cand_logp.data_ptr()
+        a.run_seq_in, a.run_seq_out = self.run_seq[i].data_ptr(), self.run_seq[o].data_ptr()
+        a.run_score_in, a.run_score_out = self.run_score[i].data_ptr(), self.run_score[o].data_ptr()
+        a.run_bidx_in, a.run_bidx_out = self.run_bidx[i].data_ptr(), self.run_bidx[o].data_ptr()
+        a.fin_seq_in, a.fin_seq_out = self.fin_seq[i].data_ptr(), self.fin_seq[o].data_ptr()
+        a.fin_score_in, a.fin_score_out = self.fin_score[i].data_ptr(), self.fin_score[o].data_ptr()
+        a.fin_bidx_in, a.fin_bidx_out = self.fin_bidx[i].data_ptr(), self.fin_bidx[o].data_ptr()
+        a.fin_done_in, a.fin_done_out = self.fin_done[i].data_ptr(), self.fin_done[o].data_ptr()
+        a.unsat = self.unsat.data_ptr()
+        a.topk_score, a.topk_parent = out.topk_scores.data_ptr(), out.topk_parent.data_ptr()
+        a.topk_token, a.topk_hit = out.topk_token.data_ptr(), out.topk_hit.data_ptr()
+        a.next_parent = out.next_parent.data_ptr()
+        index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        with torch.cuda.device(index):
+            _lib.check(_lib.lib().grx_beam_step(C.byref(a), _lib.current_stream_ptr(self.device)))
+        self.cur = o
+        self.cur_len += 1
+        return out
+
+    def has_unfinished(self) -> bool:
+        """HF's loop condition (utils.py:3055-3075).  Synchronises."""
+        out = self._outputs()
+        improvement_possible = bool(self.unsat.any())
+        exists_open_beam = not (bool(self.fin_done[self.cur].all()) and self.early_stopping is True)
+        valid_continuations = not bool(out.topk_hit.all())
+        return improvement_possible and exists_open_beam and valid_continuations
+
+    def finalize(self, num_return_sequences: Optional[int] = None):
+        """(sequences, sequences_scores, beam_indices) cropped as HF does (utils.py:3512-3523)."""
+        n = self.K if num_return_sequences is None else num_return_sequences
+        seqs = self.fin_seq[self.cur][:, :n, :].reshape(self.B * n, -1)
+        scores = self.fin_score[self.cur][:, :n].reshape(-1)
+        bidx = self.fin_bidx[self.cur][:, :n, :].reshape(self.B * n, -1)
+        gen_len = int(((bidx + 1).bool()).sum(dim=1).max())
+        return seqs[:, : self.prompt_len + gen_len], scores, bidx[:, :gen_len]
+
+
+def constrained_beam_search(
+    logits_fn: Callable[[int, torch.Tensor, Optional[torch.Tensor]], torch.Tensor],
+    processor,
+    input_ids: torch.Tensor,
+    num_beams: int,
+    max_new_tokens: int,
+    eos_token_id: Optional[int],
+    pad_token_id: Optional[int] = None,
+    length_penalty: float = 1.0,
+    early_stopping=False,
+    num_return_sequences: Optional[int] = None,
+    max_steps: Optional[int] = None,
+):
+    """Trie-constrained beam search with the fused step.
+
+    ``input_ids`` is [B, T] (one row per prompt).  ``logits_fn(step, flat_sequences,
+    next_parent)`` returns the raw next-token logits [B*K, V] for the running
+    beams (``next_parent`` is the flat KV-cache reorder index of the previous
+    step, ``None`` at step 0).  ``processor`` is a genrec_amd processor; its
+    ``candidates_into`` replaces ``log_softmax`` + mask + dense top-k.
+
+    ``max_steps`` fixes the number of iterations (a trie of L levels always
+    takes L + 1) and avoids the per-step host check of the loop condition.
+    Returns ``(state, sequences, sequences_scores, beam_indices)``.
+    """
+    prompts = input_ids.repeat_interleave(num_beams, dim=0)
+    state = BeamSearchState(prompts, num_beams, input_ids.shape[1] + max_new_tokens, eos_token_id, pad_token_id,
+                            length_penalty, early_stopping, shared_prompt=True)
+    R = state.B * num_beams
+    cmax = max(processor.trie.max_fanout, 1)
+    dev = input_ids.device
+    count = torch.empty(R, dtype=torch.int32, device=dev)
+    tok = torch.empty((R, cmax), dtype=torch.int32, device=dev)
+    logp = torch.empty((R, cmax), dtype=torch.float32, device=dev)
+    if hasattr(processor, "reset"):
+        processor.reset()
+    step = 0
+    next_parent = None
+    while True:
+        flat = state.flat_running_sequences()
+        logits = logits_fn(step, flat, next_parent)
+        processor.candidates_into(flat, logits, count, tok, logp)
+        res = state.step(count, tok, logp, logits.shape[-1])
+        next_parent = res.next_parent
+        step += 1
+        if max_steps is not None:
+            if step >= max_steps:
+                break
+        elif not state.has_unfinished():
+            break
+    seqs, scores, bidx = state.finalize(num_return_sequences)
+    return state, seqs, scores, bidx

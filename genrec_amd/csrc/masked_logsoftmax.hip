@@ -283,6 +283,43 @@ __global__ __launch_bounds__(MLS_THREADS) void masked_lsm_kernel(MlsArgs a) {
     if (OUT == OUT_COMPACT && tid == 0) a.cand_count[r] = c_n;
 }
 
+// ---- optional kernel timing ---------------------------------------------------
+#define TIMING_SLOTS 4096
+static bool g_timing_on = false;
+static int g_timing_n = 0;
+static hipEvent_t g_ev_start[TIMING_SLOTS], g_ev_stop[TIMING_SLOTS];
+static int g_ev_created = 0;
+
+extern "C" int grx_timing_enable(int on) {
+    g_timing_on = on != 0;
+    g_timing_n = 0;
+    return GRX_OK;
+}
+
+extern "C" int grx_timing_read(double* total_ms, int32_t* launches) {
+    GRX_REQUIRE(total_ms && launches, GRX_E_INVALID, "grx_timing_read: null pointer");
+    double sum = 0.0;
+    for (int i = 0; i < g_timing_n; ++i) {
+        GRX_CHECK_HIP(hipEventSynchronize(g_ev_stop[i]));
+        float ms = 0.f;
+        GRX_CHECK_HIP(hipEventElapsedTime(&ms, g_ev_start[i], g_ev_stop[i]));
+        sum += (double)ms;
+    }
+    *total_ms = sum;
+    *launches = g_timing_n;
+    return GRX_OK;
+}
+
+static int timing_slot() {
+    if (!g_timing_on || g_timing_n >= TIMING_SLOTS) return -1;
+    while (g_ev_created <= g_timing_n) {
+        if (hipEventCreate(&g_ev_start[g_ev_created]) != hipSuccess) return -1;
+        if (hipEventCreate(&g_ev_stop[g_ev_created]) != hipSuccess) return -1;
+        ++g_ev_created;
+    }
+    return g_timing_n;
+}
+
 // ---- launch -------------------------------------------------------------------
 template <int DT, int OUT>
 static void launch_vec(bool vec, const MlsArgs& a, hipStream_t stream) {
@@ -327,10 +364,16 @@ static int run_step(const char* who, const grx_trie* trie, grx_state* state, con
     a.V = rows->V;
     a.eos = con->eos_token_id;
     const bool vec = rows_16b_aligned(rows->scores, rows->scores_stride, dtype_size(rows->dtype)) && out_aligned;
+    const int slot = timing_slot();
+    if (slot >= 0) GRX_CHECK_HIP(hipEventRecord(g_ev_start[slot], stream));
     if (out_kind == OUT_COMPACT) launch_dtype<OUT_COMPACT>(rows->dtype, vec, a, stream);
     else if (out_kind == OUT_FULL_F32) launch_dtype<OUT_FULL_F32>(rows->dtype, vec, a, stream);
     else launch_dtype<OUT_FULL_SAME>(rows->dtype, vec, a, stream);
     GRX_CHECK_HIP(hipGetLastError());
+    if (slot >= 0) {
+        GRX_CHECK_HIP(hipEventRecord(g_ev_stop[slot], stream));
+        g_timing_n = slot + 1;
+    }
     return grx_state_advance(state, con->mode == GRX_MODE_COUNT, stream);
 }
 

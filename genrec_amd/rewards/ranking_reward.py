@@ -1,0 +1,223 @@
+"""Rule / prefix / NDCG rewards scored on the device.
+
+Mirror of the reference's ``rewards/ranking_reward.py`` (rule_reward 42-52,
+get_prefix_rule_reward 55-79, get_ndcg_rule_reward 82-110, build_reward_setup
+126-154): same function names (TRL matches reward functions by ``__name__``),
+same ``(prompts, completions, completion_ids, **reward_kwargs) -> list[float]``
+signature, same values.  The reference compares the integers that
+``re.findall(r"_(\\d+)")`` finds in the text (util.py:133-134); here those
+integers become int32 code rows and one kernel scores all rows of the local
+batch (``grx_sid_rewards``).
+
+``SidRewardScorer`` is the tensor-level interface for callers that already
+hold token ids on the device: it maps token ids to codes through a lookup
+table and never touches strings.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import math
+import re
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+from .. import _lib
+
+_NUM_RE = re.compile(r"_(\d+)")
+
+
+def _extract_number(text: str) -> list[int]:
+    return [int(m) for m in _NUM_RE.findall(text)]
+
+
+def _extract_reward_model_from_kwargs(reward_kwargs):
+    reward_model = reward_kwargs.get("reward_model")
+    if reward_model is not None:
+        return reward_model
+    # older callers pass (data_source, ability, reward_model, extra_info, trainer_state) positionally by key order
+    values = list(reward_kwargs.values())
+    if len(values) != 5:
+        raise ValueError("reward_model missing from reward kwargs")
+    return values[2]
+
+
+def _extract_completion_text(completion) -> str:
+    if isinstance(completion, list) and completion and isinstance(completion[0], dict):
+        return completion[0].get("content", "")
+    if isinstance(completion, dict):
+        return completion.get("content", "")
+    return str(completion)
+
+
+def _full_texts(completions, reward_kwargs) -> list[str]:
+    hints = reward_kwargs.get("oracle_hint_text")
+    texts = [_extract_completion_text(c) for c in completions]
+    if hints is not None:
+        texts = [f"{hints[i]}{t}" for i, t in enumerate(texts)]
+    return texts
+
+
+def ndcg_rank_weights(num_beams: int) -> list[float]:
+    """``-1/log2(i+2)`` normalised to sum -1, in float64 (reference: ranking_reward.py:83-84)."""
+    raw = [-1.0 / math.log2(i + 2) for i in range(num_beams)]
+    total = sum(raw)
+    return [-w / total for w in raw]
+
+
+def _pack_codes(rows: Sequence[Sequence[int]]) -> tuple[np.ndarray, np.ndarray]:
+    lens = np.fromiter((len(r) for r in rows), dtype=np.int32, count=len(rows))
+    width = max(int(lens.max()) if len(rows) else 0, 1)
+    codes = np.zeros((len(rows), width), dtype=np.int32)
+    for i, r in enumerate(rows):
+        if r:
+            codes[i, : len(r)] = r
+    return codes, lens
+
+
+def _default_device() -> torch.device:
+    if not torch.cuda.is_available():
+        raise _lib.GenrecHipError("reward scoring runs on the GPU; no HIP device is visible and there is no CPU path")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def score_code_rows(pred: torch.Tensor, pred_len: torch.Tensor, gt: torch.Tensor, gt_len: torch.Tensor, num_beams: int,
+                    prefix_normalize: bool = True, want=("rule", "prefix", "ndcg"),
+                    ndcg_weights: Optional[torch.Tensor] = None) -> dict[str, torch.Tensor]:
+    """Launch ``grx_sid_rewards`` on int32 code rows that already live on the device."""
+    for t in (pred, pred_len, gt, gt_len):
+        _lib.require_cuda(t, "reward inputs")
+        assert t.dtype == torch.int32 and t.is_contiguous()
+    R = pred.shape[0]
+    dev = pred.device
+    out = {k: torch.empty(R, dtype=torch.float32, device=dev) for k in want}
+    if "ndcg" in out:
+        out["ndcg"].fill_(float("nan"))  # rows of an incomplete trailing group get no value
+        if ndcg_weights is None:
+            ndcg_weights = torch.tensor(ndcg_rank_weights(num_beams), dtype=torch.float64).to(torch.float32).to(dev)
+    index = dev.index if dev.index is not None else torch.cuda.current_device()
+    with torch.cuda.device(index):
+        _lib.check(
+            _lib.lib().grx_sid_rewards(
+                pred.data_ptr(), pred_len.data_ptr(), pred.shape[1], gt.data_ptr(), gt_len.data_ptr(), gt.shape[1],
+                R, int(num_beams), 1 if prefix_normalize else 0,
+                ndcg_weights.data_ptr() if ndcg_weights is not None else None,
+                out["rule"].data_ptr() if "rule" in out else None,
+                out["prefix"].data_ptr() if "prefix" in out else None,
+                out["ndcg"].data_ptr() if "ndcg" in out else None,
+                _lib.current_stream_ptr(dev),
+            )
+        )
+    return out
+
+
+def _score_texts(completions, reward_kwargs, num_beams: int, prefix_normalize: bool, want) -> dict[str, list[float]]:
+    reward_model = _extract_reward_model_from_kwargs(reward_kwargs)
+    texts = _full_texts(completions, reward_kwargs)
+    pred, pred_len = _pack_codes([_extract_number(t) for t in texts])
+    gt, gt_len = _pack_codes([_extract_number(reward_model[i]["ground_truth"]) for i in range(len(texts))])
+    dev = _default_device()
+    res = score_code_rows(
+        torch.from_numpy(pred).to(dev), torch.from_numpy(pred_len).to(dev), torch.from_numpy(gt).to(dev),
+        torch.from_numpy(gt_len).to(dev), num_beams, prefix_normalize, want,
+    )
+    return {k: v.cpu().tolist() for k, v in res.items()}
+
+
+def rule_reward(prompts, completions, completion_ids, **reward_kwargs):
+    """1.0 where the completion's SID codes equal the ground truth's, else 0.0."""
+    return _score_texts(completions, reward_kwargs, 1, True, ("rule",))["rule"]
+
+
+def get_prefix_rule_reward(normalize: bool = True):
+    """Matched-prefix length before the first mismatch, divided by ``len(gt)`` when ``normalize``."""
+
+    def prefix_rule_reward(prompts, completions, completion_ids, **reward_kwargs):
+        return _score_texts(completions, reward_kwargs, 1, normalize, ("prefix",))["prefix"]
+
+    return prefix_rule_reward
+
+
+def get_ndcg_rule_reward(num_beams):
+    """Rank penalty ``w[i % num_beams]`` for non-exact rows of groups that contain an exact row."""
+
+    def ndcg_rule_reward(prompts, completions, completion_ids, **reward_kwargs):
+        vals = _score_texts(completions, reward_kwargs, num_beams, True, ("ndcg",))["ndcg"]
+        return vals[: (len(vals) // num_beams) * num_beams]  # the reference emits whole groups only
+
+    return ndcg_rule_reward
+
+
+def _append_rule_reward_probe(reward_funcs, reward_weights):
+    if any(getattr(f, "__name__", "") == "rule_reward" for f in reward_funcs):
+        return reward_funcs, reward_weights
+    reward_funcs = list(reward_funcs) + [rule_reward]
+    reward_weights = [1.0] * (len(reward_funcs) - 1) if reward_weights is None else list(reward_weights)
+    reward_weights.append(0.0)
+    return reward_funcs, reward_weights
+
+
+def build_reward_setup(reward_mode: str, num_beams: int, prefix_reward_normalize: bool = True,
+                       probe_rule_with_zero_weight: bool = False):
+    """(reward_funcs, reward_weights) per mode (reference: ranking_reward.py:126-154)."""
+    mode = reward_mode.strip().lower()
+    prefix_func = get_prefix_rule_reward(normalize=prefix_reward_normalize)
+    ndcg_func = get_ndcg_rule_reward(num_beams)
+    if mode == "rule_only":
+        return [rule_reward], None
+    if mode == "ranking_only":
+        return _append_rule_reward_probe([ndcg_func], None)
+    if mode == "prefix_rule_only":
+        return _append_rule_reward_probe([prefix_func], None)
+    if mode == "prefix_only":
+        return _append_rule_reward_probe([prefix_func, ndcg_func], None)
+    if mode == "prefix_ranking":
+        return [prefix_func, rule_reward, ndcg_func], None
+    if mode == "ranking":
+        return [rule_reward, ndcg_func], None
+    raise ValueError(
+        f"Unsupported reward_mode={reward_mode}. "
+        "Use one of: ranking, rule_only, ranking_only, prefix_rule_only, prefix_only, prefix_ranking."
+    )
+
+
+def build_reward_funcs(reward_mode: str, num_beams: int, prefix_reward_normalize: bool = True):
+    return build_reward_setup(reward_mode, num_beams, prefix_reward_normalize, False)[0]
+
+
+class SidRewardScorer:
+    """Rewards straight from token ids on the device.
+
+    ``code_table[token_id]`` is the integer after ``_`` in the token's text
+    (-1 for tokens that carry no SID code, e.g. EOS / padding).  Tokens with
+    code -1 are dropped, like text the regular expression does not match.
+    """
+
+    def __init__(self, code_table, num_beams: int, device=None, prefix_normalize: bool = True):
+        self.device = torch.device(device) if device is not None else _default_device()
+        self.table = torch.as_tensor(np.asarray(code_table), dtype=torch.int32).to(self.device)
+        self.num_beams = int(num_beams)
+        self.prefix_normalize = prefix_normalize
+        self.ndcg_weights = torch.tensor(ndcg_rank_weights(self.num_beams), dtype=torch.float64).to(torch.float32).to(
+            self.device
+        )
+
+    def codes(self, token_ids: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+        """token ids [R, L] -> (codes [R, L] int32 with SID codes packed left, lengths [R])."""
+        ids = token_ids.to(self.device).long().clamp_(0, self.table.shape[0] - 1)
+        codes = self.table[ids]
+        valid = codes >= 0
+        order = torch.argsort((~valid).to(torch.int8), dim=1, stable=True)  # SID codes first, original order kept
+        packed = torch.gather(codes, 1, order)
+        lens = valid.sum(dim=1).to(torch.int32)
+        return packed.contiguous(), lens.contiguous()
+
+    def __call__(self, completion_ids: torch.Tensor, gt_ids: torch.Tensor, hint_ids: Optional[torch.Tensor] = None,
+                 want=("rule", "prefix", "ndcg")) -> dict[str, torch.Tensor]:
+        full = completion_ids if hint_ids is None else torch.cat([hint_ids.to(completion_ids.device), completion_ids], 1)
+        pred, pred_len = self.codes(full)
+        gt, gt_len = self.codes(gt_ids)
+        return score_code_rows(pred, pred_len, gt, gt_len, self.num_beams, self.prefix_normalize, want,
+                               self.ndcg_weights)

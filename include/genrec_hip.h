@@ -151,6 +151,16 @@ GRX_API int grx_constrained_candidates(const grx_trie* trie, grx_state* state, c
                                float* cand_logp, int32_t cmax, void* workspace, size_t workspace_bytes,
                                void* stream);
 
+/*
+ * Kernel timing for benchmarks (no counterpart in the reference).  While
+ * enabled, the two calls above bracket their streaming kernel -- and only that
+ * kernel -- with HIP events on the caller's stream (up to 4096 launches per
+ * enable).  grx_timing_read synchronises on the recorded events and returns
+ * the summed kernel time in milliseconds and the number of launches.
+ */
+GRX_API int grx_timing_enable(int on);
+GRX_API int grx_timing_read(double* total_ms, int32_t* launches);
+
 /* -------------------------------------------------------------- beam step --- */
 
 /*

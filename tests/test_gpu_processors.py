@@ -1,0 +1,289 @@
+"""GPU parity of the constrained processors (through the C ABI) against the
+golden vectors captured from the reference and against the CPU oracle."""
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import load_json_gz, load_npz, write_index_file
+
+pytestmark = pytest.mark.gpu
+
+FP32_TOL = 1e-5   # log-probs from fp32 logits
+BF16_TOL = 2e-3   # log-probs from bf16 logits
+
+
+def _dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda", 0)
+
+
+def _small_setup():
+    from genrec_amd.trie import FlatTrie, create_prefix_allowed_tokens_fn
+
+    data, meta = load_npz("processors.npz")
+    trie = FlatTrie(data["trie_sequences"].tolist())
+    fn = create_prefix_allowed_tokens_fn(trie, meta["prefix"])
+    return data, meta, trie, fn
+
+
+def _assert_dense_close(got: torch.Tensor, want: np.ndarray, tol: float):
+    got = got.float().cpu().numpy()
+    finite_w = np.isfinite(want)
+    assert np.array_equal(np.isfinite(got), finite_w), "allowed-token sets differ"
+    assert np.all(got[~finite_w] == -np.inf)
+    assert np.max(np.abs(got[finite_w] - want[finite_w])) <= tol
+
+
+def _make(case, fn, meta, **kw):
+    from genrec_amd.fixed_hint_logit_processor import FixedHintConstrainedLogitsProcessor
+    from genrec_amd.logit_processor import ConstrainedLogitsProcessor
+
+    K, prefix, eos = meta["K"], meta["prefix"], meta["eos"]
+    if case == "count_rl" or case == "count_midloop_reset":
+        return ConstrainedLogitsProcessor(fn, K, 3, prefix, eos, **kw)
+    if case == "count_eval":
+        return ConstrainedLogitsProcessor(fn, K, 3, None, eos, **kw)
+    if case == "count_seeded2":
+        return ConstrainedLogitsProcessor(fn, K, 3, prefix, eos, initial_count=2, **kw)
+    if case == "fixed_hint":
+        return FixedHintConstrainedLogitsProcessor(fn, K, 3, prefix, eos, **kw)
+    raise KeyError(case)
+
+
+@pytest.mark.parametrize("case", ["count_rl", "count_eval", "count_seeded2", "count_midloop_reset", "fixed_hint"])
+def test_processor_matches_reference_golden(case):
+    data, meta, trie, fn = _small_setup()
+    dev = _dev()
+    proc = _make(case, fn, meta)
+    info = meta["cases"][case]
+    for i in range(info["steps"]):
+        ids = torch.from_numpy(data[f"{case}.ids.{i}"]).to(dev)
+        scores = torch.from_numpy(data[f"{case}.scores.{i}"]).to(dev)
+        before = scores.clone()
+        out = proc(ids, scores)
+        assert out.shape == scores.shape and out.dtype == scores.dtype and out.data_ptr() != scores.data_ptr()
+        assert torch.equal(scores, before), "inputs must not be modified"
+        _assert_dense_close(out, data[f"{case}.out.{i}"], FP32_TOL)
+        if info["counts_after"][i] >= 0:
+            assert proc.count == info["counts_after"][i]
+    proc.check_errors()
+
+
+@pytest.mark.parametrize("case", ["count_rl", "fixed_hint"])
+def test_candidates_match_dense_golden(case):
+    """The fused (compact) entry point returns exactly the finite columns of the dense result."""
+    data, meta, trie, fn = _small_setup()
+    dev = _dev()
+    proc = _make(case, fn, meta)
+    for i in range(meta["cases"][case]["steps"]):
+        ids = torch.from_numpy(data[f"{case}.ids.{i}"]).to(dev)
+        scores = torch.from_numpy(data[f"{case}.scores.{i}"]).to(dev)
+        count, tok, logp = proc.candidates(ids, scores)
+        want = data[f"{case}.out.{i}"]
+        count, tok, logp = count.cpu().numpy(), tok.cpu().numpy(), logp.cpu().numpy()
+        for r in range(want.shape[0]):
+            cols = np.nonzero(np.isfinite(want[r]))[0]
+            assert count[r] == len(cols)
+            assert np.array_equal(tok[r, : count[r]], cols)  # bit-exact token ids, ascending
+            assert np.max(np.abs(logp[r, : count[r]] - want[r, cols])) <= FP32_TOL
+
+
+def test_reference_error_conventions():
+    data, meta, trie, fn = _small_setup()
+    dev = _dev()
+    from genrec_amd.fixed_hint_logit_processor import FixedHintConstrainedLogitsProcessor
+    from genrec_amd.logit_processor import ConstrainedLogitsProcessor
+
+    K, prefix, eos, V = meta["K"], meta["prefix"], meta["eos"], meta["V"]
+    bad = torch.from_numpy(data["bad_rows"]).to(dev)
+    scores = torch.randn(bad.shape[0], V, device=dev)
+    want = {e["processor"]: e for e in meta["errors"]}
+
+    proc = ConstrainedLogitsProcessor(fn, K, 3, None, eos, sync_errors=True)
+    proc.count = 1
+    with pytest.raises(AssertionError, match="No valid tokens for prefix_ids"):
+        proc(bad, scores)
+    assert want["count"]["type"] == "AssertionError"
+
+    fixed = FixedHintConstrainedLogitsProcessor(fn, K, 3, prefix, eos, sync_errors=True)
+    with pytest.raises(ValueError, match="Failed to find a valid trie prefix match"):
+        fixed(bad, scores)
+    assert want["fixed"]["type"] == "ValueError"
+    nop = torch.from_numpy(data["noprefix_rows"]).to(dev)
+    with pytest.raises(ValueError, match="Failed to find a valid trie prefix match"):
+        fixed(nop, scores)
+
+    # lazy mode: the failure surfaces at reset() / count
+    lazy = ConstrainedLogitsProcessor(fn, K, 3, None, eos, sync_errors=False)
+    lazy.count = 1
+    lazy(bad, scores)
+    with pytest.raises(AssertionError):
+        lazy.reset()
+    lazy.reset()  # the error was consumed
+    assert lazy.count == 0
+
+    with pytest.raises(AssertionError, match="input_ids must be a 2D tensor"):
+        proc(bad[0], scores)
+    with pytest.raises(RuntimeError):
+        proc(bad[:5], scores[:5])  # rows not a multiple of num_beams
+    with pytest.raises(Exception, match="GPU"):
+        proc(bad.cpu(), scores.cpu())  # no CPU path
+
+
+def test_count_attribute_protocol():
+    """reset()/count as MIMIGenRec.generate and evaluate.py drive them
+    (reference: MIMIGenRec.py:26-33, evaluate.py:358-361)."""
+    data, meta, trie, fn = _small_setup()
+    dev = _dev()
+    from genrec_amd.logit_processor import ConstrainedLogitsProcessor
+
+    proc = ConstrainedLogitsProcessor(fn, meta["K"], 3, None, meta["eos"])
+    assert hasattr(proc, "count") and proc.count == 0
+    ids = torch.from_numpy(data["count_eval.ids.0"]).to(dev)
+    scores = torch.from_numpy(data["count_eval.scores.0"]).to(dev)
+    proc(ids, scores)
+    assert proc.count == 1
+    proc.count = 0
+    assert proc.count == 0
+    proc(ids, scores)
+    proc.reset()
+    assert proc.count == 0
+
+
+def test_full_vocab_rows_fp32_and_bf16(tmp_path):
+    """Real Instruments trie at V=152,640: allowed ids bit-exact, log-probs within tolerance."""
+    from genrec_amd.logit_processor import ConstrainedLogitsProcessor
+    from genrec_amd.synth import ASSISTANT_PREFIX, SidTokenizer
+    from genrec_amd.trie import build_trie_from_index, create_prefix_allowed_tokens_fn
+
+    dev = _dev()
+    data, meta = load_npz("full_vocab_rows.npz")
+    path = write_index_file("Instruments", tmp_path)
+    tok = SidTokenizer.from_index(path)
+    trie, suffix, pidx = build_trie_from_index(path, tok, prefix=ASSISTANT_PREFIX)
+    tries = load_json_gz("tries.json.gz")["Instruments"]
+    assert (trie.n_nodes, trie.max_fanout, tok.vocab_size_padded) == (tries["n_nodes"], tries["max_fanout"], meta["V"])
+    fn = create_prefix_allowed_tokens_fn(trie, suffix)
+    K, V = meta["K"], meta["V"]
+    p32 = ConstrainedLogitsProcessor(fn, K, pidx, suffix, tok.eos_token_id)
+    p16 = ConstrainedLogitsProcessor(fn, K, pidx, suffix, tok.eos_token_id)
+
+    def check(tk, lp, n, want_tok, want_lp, exact, tol):
+        """Token ids bit-exact.  Log-probs: within `tol` of the exactly evaluated
+        log-softmax, and within `tol` + the reference's own fp32 summation error of the
+        captured reference output (PyTorch-CPU sums 152k terms sequentially per SIMD lane
+        and lands 1-2e-5 away from the float64 value at this width)."""
+        tk, lp = tk.cpu().numpy(), lp.cpu().numpy()
+        for r in range(tk.shape[0]):
+            cols = want_tok[r, : n[r]]
+            assert np.array_equal(tk[r, : n[r]], cols)
+            ex = exact[r, cols]
+            ref_err = float(np.max(np.abs(want_lp[r, : n[r]] - ex)))
+            assert np.max(np.abs(lp[r, : n[r]] - ex)) <= tol
+            assert np.max(np.abs(lp[r, : n[r]] - want_lp[r, : n[r]])) <= tol + ref_err
+
+    for step in range(meta["steps"]):
+        ids = torch.from_numpy(data[f"ids.{step}"]).to(dev)
+        gen = torch.Generator().manual_seed(meta["seed"] + step)
+        logits = torch.randn(ids.shape[0], V, generator=gen) * meta["scale"]
+        n = data[f"count.{step}"]
+        count, tk, lp = p32.candidates(ids, logits.to(dev), cmax=trie.max_fanout)
+        assert np.array_equal(count.cpu().numpy(), n)
+        exact = torch.log_softmax(logits.double(), dim=-1).numpy()
+        check(tk, lp, n, data[f"tok.{step}"], data[f"logp.{step}"], exact, FP32_TOL)
+
+        l16 = logits.to(torch.bfloat16)
+        c16, t16, lp16 = p16.candidates(ids, l16.to(dev), cmax=trie.max_fanout)
+        assert np.array_equal(c16.cpu().numpy(), n)
+        exact16 = torch.log_softmax(l16.double(), dim=-1).numpy()
+        check(t16, lp16, n, data[f"tok.{step}"], data[f"logp_bf16.{step}"], exact16, BF16_TOL)
+        # for bf16 logits the fp32 tolerance holds as well: the inputs are exactly representable
+        check(t16, lp16, n, data[f"tok.{step}"], data[f"logp_bf16.{step}"], exact16, FP32_TOL)
+
+        # dense surface on bf16 input keeps the dtype
+        dense = ConstrainedLogitsProcessor(fn, K, pidx, None, tok.eos_token_id)
+        dense.count = step
+        out = dense(ids, l16.to(dev))
+        assert out.dtype == torch.bfloat16
+        assert np.array_equal(torch.isfinite(out).sum(dim=1).cpu().numpy(), n)
+    p32.check_errors()
+    p16.check_errors()
+
+
+@pytest.mark.parametrize("V", [1000, 1001, 1023, 4099])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+def test_ragged_vocab_widths_against_oracle(V, dtype):
+    """Rows whose width breaks 16-byte alignment take the element-wise path; results match the oracle."""
+    from oracle.processors import DictTrie, RefConstrainedLogitsProcessor
+
+    from genrec_amd.logit_processor import ConstrainedLogitsProcessor
+    from genrec_amd.trie import FlatTrie, create_prefix_allowed_tokens_fn
+
+    data, meta, _, _ = _small_setup()
+    dev = _dev()
+    seqs = data["trie_sequences"].tolist()
+    trie = FlatTrie(seqs)
+    fn = create_prefix_allowed_tokens_fn(trie, meta["prefix"])
+    o_trie = DictTrie(seqs)
+    K = meta["K"]
+    ids = torch.from_numpy(data["count_rl.ids.1"])
+    torch.manual_seed(V)
+    scores = (torch.randn(ids.shape[0], V) * 5).to(dtype)
+    ref = RefConstrainedLogitsProcessor(o_trie.get, K, 3, meta["prefix"], meta["eos"])
+    ref.count = 1
+    want = ref(ids, scores.float())
+    proc = ConstrainedLogitsProcessor(fn, K, 3, meta["prefix"], meta["eos"])
+    proc.count = 1
+    got = proc(ids.to(dev), scores.to(dev))
+    assert got.dtype == dtype
+    tol = FP32_TOL if dtype == torch.float32 else (BF16_TOL if dtype == torch.float16 else None)
+    got32 = got.float().cpu()
+    assert torch.equal(torch.isfinite(got32), torch.isfinite(want))
+    if tol is None:  # bf16 output: one bf16 rounding of the fp32 value
+        assert torch.equal(got32[torch.isfinite(want)], want[torch.isfinite(want)].to(torch.bfloat16).float()) or (
+            (got32 - want)[torch.isfinite(want)].abs().max() <= 0.07
+        )
+    else:
+        lim = tol if dtype == torch.float32 else 1e-2  # fp16 output rounding
+        assert (got32 - want)[torch.isfinite(want)].abs().max() <= lim
+    c, t, lp = proc.candidates(ids.to(dev), scores.to(dev))  # count advanced to 2 -> rewind first
+    proc.count = 1
+    c, t, lp = proc.candidates(ids.to(dev), scores.to(dev))
+    for r in range(ids.shape[0]):
+        cols = torch.nonzero(torch.isfinite(want[r])).flatten()
+        assert c[r].item() == cols.numel()
+        assert torch.equal(t[r, : cols.numel()].cpu().long(), cols)
+        assert (lp[r, : cols.numel()].cpu() - want[r, cols]).abs().max() <= FP32_TOL
+
+
+def test_strided_inputs_and_unnormalised_extremes():
+    """Non-contiguous views, very peaked rows and rows containing -inf."""
+    from oracle.processors import DictTrie, RefFixedHintConstrainedLogitsProcessor
+
+    from genrec_amd.fixed_hint_logit_processor import FixedHintConstrainedLogitsProcessor
+    from genrec_amd.trie import FlatTrie, create_prefix_allowed_tokens_fn
+
+    data, meta, _, _ = _small_setup()
+    dev = _dev()
+    seqs = data["trie_sequences"].tolist()
+    fn = create_prefix_allowed_tokens_fn(FlatTrie(seqs), meta["prefix"])
+    o_trie = DictTrie(seqs)
+    K, V = meta["K"], meta["V"]
+    ids = torch.from_numpy(data["fixed_hint.ids.1"])
+    R = ids.shape[0]
+    torch.manual_seed(3)
+    big = torch.randn(R, V + 64) * 30.0
+    big[0, :10] = float("-inf")
+    big[1, 5] = 80.0
+    big[2] = -1e4
+    scores = big[:, 32 : 32 + V]  # row stride V + 64, 16-byte aligned start
+    wide_ids = torch.zeros(R, ids.shape[1] + 5, dtype=torch.int64)
+    wide_ids[:, : ids.shape[1]] = ids
+    ref = RefFixedHintConstrainedLogitsProcessor(o_trie.get, K, 3, meta["prefix"], meta["eos"])
+    want = ref(ids, scores.contiguous())
+    proc = FixedHintConstrainedLogitsProcessor(fn, K, 3, meta["prefix"], meta["eos"], sync_errors=True)
+    got = proc(wide_ids.to(dev)[:, : ids.shape[1]], big.to(dev)[:, 32 : 32 + V]).cpu()
+    assert torch.equal(torch.isfinite(got), torch.isfinite(want))
+    fin = torch.isfinite(want)
+    assert (got - want)[fin].abs().max() <= 2e-5 * max(1.0, float(want[fin].abs().max()) / 10)
