@@ -39,7 +39,9 @@ EXPORTED_SYMBOLS = (
     "grx_timing_enable",
     "grx_timing_read",
     "grx_beam_step",
+    "grx_beam_init",
     "grx_sid_rewards",
+    "grx_sid_rewards_tokens",
     "grx_hit_ranks",
     "grx_group_advantage",
     "grx_group_normalize_tokenwise",
@@ -109,6 +111,26 @@ class GrxBeamStepArgs(C.Structure):
     ]
 
 
+class GrxBeamInitArgs(C.Structure):
+    _fields_ = [
+        ("B", C.c_int32),
+        ("K", C.c_int32),
+        ("prompt_len", C.c_int32),
+        ("max_length", C.c_int32),
+        ("fill_token", C.c_int64),
+        ("input_ids", C.c_void_p),
+        ("ids_stride", C.c_int64),
+        ("run_seq", C.c_void_p * 2),
+        ("fin_seq", C.c_void_p * 2),
+        ("run_score", C.c_void_p * 2),
+        ("fin_score", C.c_void_p * 2),
+        ("run_bidx", C.c_void_p * 2),
+        ("fin_bidx", C.c_void_p * 2),
+        ("fin_done", C.c_void_p * 2),
+        ("unsat", C.c_void_p),
+    ]
+
+
 _lock = threading.Lock()
 _lib = None
 
@@ -157,8 +179,12 @@ def _declare(lib: C.CDLL) -> None:
     lib.grx_timing_read.argtypes = [C.POINTER(C.c_double), C.POINTER(i32)]
     lib.grx_beam_step.restype = C.c_int
     lib.grx_beam_step.argtypes = [C.POINTER(GrxBeamStepArgs), vp]
+    lib.grx_beam_init.restype = C.c_int
+    lib.grx_beam_init.argtypes = [C.POINTER(GrxBeamInitArgs), vp]
     lib.grx_sid_rewards.restype = C.c_int
-    lib.grx_sid_rewards.argtypes = [vp, vp, i32, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]
+    lib.grx_sid_rewards.argtypes = [vp, vp, i32, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, i32, vp]
+    lib.grx_sid_rewards_tokens.restype = C.c_int
+    lib.grx_sid_rewards_tokens.argtypes = [vp, i64, i32, vp, i64, i32, vp, i32, i32, i32, i32, vp, vp, vp, vp, i32, vp]
     lib.grx_hit_ranks.restype = C.c_int
     lib.grx_hit_ranks.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp]
     lib.grx_group_advantage.restype = C.c_int

@@ -61,27 +61,53 @@ class BeamSearchState:
         # when every beam of a group starts from the same prompt, re-ordering beams never changes
         # positions < prompt_len, so the kernel only moves the generated suffix
         self.copy_from = cur_len if shared_prompt else 0
-        fill = (pad_token_id or eos_token_id) if eos_token_id is not None else -1
-        B, K = self.B, self.K
+        self.fill = (pad_token_id or eos_token_id) if eos_token_id is not None else -1
+        B, K, L = self.B, self.K, self.max_length
+        lg = L - cur_len
 
-        def both(t):
-            return [t, t.clone()]
+        def pair(shape, dtype):
+            return [torch.empty(shape, dtype=dtype, device=dev) for _ in range(2)]
 
-        run_seq = torch.full((B, K, self.max_length), fill, dtype=torch.int64, device=dev)
-        run_seq[:, :, :cur_len] = input_ids.view(B, K, cur_len)
-        self.run_seq = both(run_seq)
-        self.fin_seq = both(run_seq.clone())
-        run_score = torch.zeros((B, K), dtype=torch.float32, device=dev)
-        run_score[:, 1:] = NEG
-        self.run_score = both(run_score)
-        self.fin_score = both(torch.full((B, K), NEG, dtype=torch.float32, device=dev))
-        lg = self.max_length - cur_len
-        self.run_bidx = both(torch.full((B, K, lg), -1, dtype=torch.int32, device=dev))
-        self.fin_bidx = both(torch.full((B, K, lg), -1, dtype=torch.int32, device=dev))
-        self.fin_done = both(torch.zeros((B, K), dtype=torch.uint8, device=dev))
-        self.unsat = torch.ones(B, dtype=torch.uint8, device=dev)
-        self.cur = 0  # index of the buffer that holds the current state
+        self.run_seq = pair((B, K, L), torch.int64)
+        self.fin_seq = pair((B, K, L), torch.int64)
+        self.run_score = pair((B, K), torch.float32)
+        self.fin_score = pair((B, K), torch.float32)
+        self.run_bidx = pair((B, K, lg), torch.int32)
+        self.fin_bidx = pair((B, K, lg), torch.int32)
+        self.fin_done = pair((B, K), torch.uint8)
+        self.unsat = torch.empty(B, dtype=torch.uint8, device=dev)
         self._step_out = None
+        self.reset(input_ids)
+
+    def reset(self, input_ids: torch.Tensor) -> None:
+        """Start a new search from ``input_ids`` [B*K, prompt_len] (same shape as at
+        construction) in the existing buffers: one kernel launch, no allocation."""
+        _lib.require_cuda(input_ids, "input_ids")
+        if tuple(input_ids.shape) != (self.B * self.K, self.prompt_len):
+            raise ValueError("reset() needs input_ids of the shape the state was built for")
+        if input_ids.dtype != torch.int64:
+            input_ids = input_ids.to(torch.int64)
+        if input_ids.stride(1) != 1:
+            input_ids = input_ids.contiguous()
+        a = _lib.GrxBeamInitArgs()
+        a.B, a.K, a.prompt_len, a.max_length = self.B, self.K, self.prompt_len, self.max_length
+        a.fill_token = int(self.fill)
+        a.input_ids = input_ids.data_ptr()
+        a.ids_stride = input_ids.stride(0) if input_ids.shape[0] > 1 else max(self.prompt_len, 1)
+        for h in range(2):
+            a.run_seq[h] = self.run_seq[h].data_ptr()
+            a.fin_seq[h] = self.fin_seq[h].data_ptr()
+            a.run_score[h] = self.run_score[h].data_ptr()
+            a.fin_score[h] = self.fin_score[h].data_ptr()
+            a.run_bidx[h] = self.run_bidx[h].data_ptr()
+            a.fin_bidx[h] = self.fin_bidx[h].data_ptr()
+            a.fin_done[h] = self.fin_done[h].data_ptr()
+        a.unsat = self.unsat.data_ptr()
+        index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        with torch.cuda.device(index):
+            _lib.check(_lib.lib().grx_beam_init(C.byref(a), _lib.current_stream_ptr(self.device)))
+        self.cur = 0  # index of the buffer that holds the current state
+        self.cur_len = self.prompt_len
 
     # -- views of the current state -------------------------------------------------
     @property

@@ -13,7 +13,8 @@
 #define BS_WAVES (BS_THREADS / GRX_WAVE)
 #define BS_MAXK 256
 #define BS_MAXKEEP 512
-#define BS_LDS_KEYS_MAX 16384  // 128 KiB of staged 64-bit keys at most
+#define BS_LDS_KEYS_MAX 8192   // 64 KiB of staged 64-bit keys at most
+#define BS_SURV_CAP 1024       // candidates ranked pairwise after the threshold cut
 
 struct BeamDerived {
     float fin_div;    // (cur_len + 1 - prompt_len) ** length_penalty
@@ -32,6 +33,12 @@ __device__ __forceinline__ bool ranks_before(float va, int ia, float vb, int ib)
 __global__ __launch_bounds__(BS_THREADS) void beam_step_kernel(grx_beam_step_args a, BeamDerived d) {
     extern __shared__ unsigned long long s_keys[];
     __shared__ int s_pre[BS_MAXK + 1];
+    __shared__ int s_cnt[BS_MAXK];
+    __shared__ float s_runin[BS_MAXK];
+    __shared__ unsigned long long s_tmax[BS_THREADS];
+    __shared__ unsigned long long s_surv[BS_SURV_CAP];
+    __shared__ int s_nsurv;
+    __shared__ unsigned long long s_thresh;
     __shared__ unsigned long long s_red[2][BS_WAVES];
     __shared__ float s_score[BS_MAXKEEP];
     __shared__ int s_parent[BS_MAXKEEP];
@@ -52,72 +59,141 @@ __global__ __launch_bounds__(BS_THREADS) void beam_step_kernel(grx_beam_step_arg
     const int64_t row0 = (int64_t)b * K;
 
     // ---- candidate layout: prefix sums of the per-beam counts
+    for (int k = tid; k < K; k += BS_THREADS) {
+        s_cnt[k] = a.cand_count[row0 + k];
+        s_runin[k] = a.run_score_in[row0 + k];
+    }
+    __syncthreads();
     if (tid == 0) {
         int acc = 0;
         for (int k = 0; k < K; ++k) {
             s_pre[k] = acc;
-            acc += a.cand_count[row0 + k];
+            acc += s_cnt[k];
         }
         s_pre[K] = acc;
+        s_nsurv = 0;
+        s_thresh = 0;
     }
     __syncthreads();
     const int N = s_pre[K];
     const bool staged = N <= d.lds_keys;
 
-    auto key_of = [&](int c) -> unsigned long long {
-        int lo = 0, hi = K;  // largest k with s_pre[k] <= c
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (s_pre[mid] <= c) lo = mid; else hi = mid;
+    auto key_of = [&](int c) -> unsigned long long {  // candidate c in flat (beam, position) order
+        int k = 0;  // largest k with s_pre[k] <= c
+#pragma unroll
+        for (int stepk = BS_MAXK / 2; stepk > 0; stepk >>= 1) {
+            const int cand = k + stepk;
+            if (cand < K && s_pre[cand] <= c) k = cand;
         }
-        const int k = lo;
         const int64_t at = (row0 + k) * cmax + (c - s_pre[k]);
-        const float score = a.cand_logp[at] + a.run_score_in[row0 + k];
-        return make_key(score, (uint32_t)k * (uint32_t)V + (uint32_t)a.cand_tok[at]);
+        return make_key(a.cand_logp[at] + s_runin[k], (uint32_t)k * (uint32_t)V + (uint32_t)a.cand_tok[at]);
+    };
+    auto emit = [&](int j, unsigned long long key) {
+        if (key == 0) {  // fewer candidates than n_keep: a -inf filler slot
+            s_score[j] = -INFINITY;
+            s_parent[j] = 0;
+            s_tok[j] = 0;
+        } else {
+            const uint32_t flat = 0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull);
+            s_score[j] = ordered_to_float((uint32_t)(key >> 32));
+            s_parent[j] = (int)(flat / (uint32_t)V);
+            s_tok[j] = (int)(flat % (uint32_t)V);
+        }
     };
 
+    // ---- top n_keep by (score desc, beam * V + token asc).  Keys are unique, so
+    // the rank of a key is the number of larger keys.  Fast path: a threshold
+    // (the n_keep-th largest of the per-thread maxima, which at least n_keep keys
+    // reach) leaves a few dozen survivors; they are ranked against each other.
+    bool selected = false;
     if (staged) {
-        for (int c = tid; c < N; c += BS_THREADS) s_keys[c] = key_of(c);
-        __syncthreads();
-    }
-
-    // ---- top n_keep by (score desc, beam * V + token asc): n_keep rounds of
-    // "largest key below the previous winner"; keys are unique.
-    unsigned long long prev = ~0ull;
-    for (int j = 0; j < n_keep; ++j) {
-        unsigned long long best = 0;
-        if (prev != 0) {
-            if (staged) {
-                for (int c = tid; c < N; c += BS_THREADS) {
-                    const unsigned long long kv = s_keys[c];
-                    if (kv < prev && kv > best) best = kv;
-                }
-            } else {
-                for (int c = tid; c < N; c += BS_THREADS) {
-                    const unsigned long long kv = key_of(c);
-                    if (kv < prev && kv > best) best = kv;
-                }
-            }
-            best = wave_max_u64(best);
-            if (lane == 0) s_red[j & 1][wave] = best;
-            __syncthreads();
-            best = s_red[j & 1][0];
+        int widest = 0;
+        for (int k = 0; k < K; ++k) widest = s_cnt[k] > widest ? s_cnt[k] : widest;
+        for (int i = tid; i < widest; i += BS_THREADS) {
+            // four beams per batch so that their candidate loads are in flight together
+            for (int k0 = 0; k0 < K; k0 += 4) {
+                float lp[4];
+                int tk[4];
 #pragma unroll
-            for (int w = 1; w < BS_WAVES; ++w) best = s_red[j & 1][w] > best ? s_red[j & 1][w] : best;
-        }
-        if (tid == 0) {
-            if (best == 0) {  // fewer candidates than n_keep: a -inf filler slot
-                s_score[j] = -INFINITY;
-                s_parent[j] = 0;
-                s_tok[j] = 0;
-            } else {
-                const uint32_t flat = 0xFFFFFFFFu - (uint32_t)(best & 0xFFFFFFFFull);
-                s_score[j] = ordered_to_float((uint32_t)(best >> 32));
-                s_parent[j] = (int)(flat / (uint32_t)V);
-                s_tok[j] = (int)(flat % (uint32_t)V);
+                for (int u = 0; u < 4; ++u) {
+                    const int k = k0 + u;
+                    const bool ok = k < K && i < s_cnt[k];
+                    const int64_t at = ok ? (row0 + k) * cmax + i : row0 * cmax;
+                    lp[u] = a.cand_logp[at];
+                    tk[u] = a.cand_tok[at];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int k = k0 + u;
+                    if (k < K && i < s_cnt[k]) {
+                        const unsigned long long kv =
+                            make_key(lp[u] + s_runin[k], (uint32_t)k * (uint32_t)V + (uint32_t)tk[u]);
+                        s_keys[s_pre[k] + i] = kv;
+                    }
+                }
             }
         }
-        prev = best;
+        __syncthreads();
+        // per-thread maxima over a strided slice of the staged keys (every thread owns one when N > threads)
+        unsigned long long tmax = 0;
+        for (int c = tid; c < N; c += BS_THREADS) tmax = s_keys[c] > tmax ? s_keys[c] : tmax;
+        const bool prefilter = N > BS_THREADS && n_keep <= BS_THREADS;  // every thread then holds a key
+        if (prefilter) {
+            s_tmax[tid] = tmax;
+            __syncthreads();
+            int rank = 0;
+            for (int j = 0; j < BS_THREADS; ++j) rank += s_tmax[j] > tmax ? 1 : 0;
+            if (rank == n_keep - 1) s_thresh = tmax;
+        }
+        __syncthreads();
+        const unsigned long long thresh = s_thresh;
+        for (int c = tid; c < N; c += BS_THREADS) {
+            const unsigned long long kv = s_keys[c];
+            if (kv >= thresh) {
+                const int at = atomicAdd(&s_nsurv, 1);
+                if (at < BS_SURV_CAP) s_surv[at] = kv;
+            }
+        }
+        __syncthreads();
+        const int M = s_nsurv;
+        if (M <= BS_SURV_CAP) {
+            for (int i = tid; i < M; i += BS_THREADS) {
+                const unsigned long long kv = s_surv[i];
+                int rank = 0;
+                for (int j = 0; j < M; ++j) rank += s_surv[j] > kv ? 1 : 0;
+                if (rank < n_keep) emit(rank, kv);
+            }
+            for (int j = M + tid; j < n_keep; j += BS_THREADS) emit(j, 0);
+            selected = true;
+        }
+    }
+    if (!selected) {
+        // general path: n_keep rounds of "largest key below the previous winner"
+        unsigned long long prev = ~0ull;
+        for (int j = 0; j < n_keep; ++j) {
+            unsigned long long best = 0;
+            if (prev != 0) {
+                if (staged) {
+                    for (int c = tid; c < N; c += BS_THREADS) {
+                        const unsigned long long kv = s_keys[c];
+                        if (kv < prev && kv > best) best = kv;
+                    }
+                } else {
+                    for (int c = tid; c < N; c += BS_THREADS) {
+                        const unsigned long long kv = key_of(c);
+                        if (kv < prev && kv > best) best = kv;
+                    }
+                }
+                best = wave_max_u64(best);
+                if (lane == 0) s_red[j & 1][wave] = best;
+                __syncthreads();
+                best = s_red[j & 1][0];
+#pragma unroll
+                for (int w = 1; w < BS_WAVES; ++w) best = s_red[j & 1][w] > best ? s_red[j & 1][w] : best;
+            }
+            if (tid == 0) emit(j, best);
+            prev = best;
+        }
     }
     __syncthreads();
 
@@ -282,6 +358,64 @@ extern "C" int grx_beam_step(const grx_beam_step_args* args, void* stream) {
                                           (int)lds_bytes));
     }
     hipLaunchKernelGGL(beam_step_kernel, dim3(a.B), dim3(BS_THREADS), lds_bytes, (hipStream_t)stream, a, d);
+    GRX_CHECK_HIP(hipGetLastError());
+    return GRX_OK;
+}
+
+// ------------------------------------------------------------------ init ---
+// Initial beam-search state (transformers generation/utils.py:3316-3351) written
+// into both halves of every double buffer by one launch.
+__global__ void beam_init_kernel(grx_beam_init_args a) {
+    const int64_t R = (int64_t)a.B * a.K;
+    const int L = a.max_length, Lg = a.max_length - a.prompt_len;
+    const int64_t total = R * L;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / L;
+        const int p = (int)(i % L);
+        const int64_t v = p < a.prompt_len ? a.input_ids[r * a.ids_stride + p] : a.fill_token;
+        a.run_seq[0][i] = v;
+        a.run_seq[1][i] = v;
+        a.fin_seq[0][i] = v;
+        a.fin_seq[1][i] = v;
+        if (p < Lg) {
+            const int64_t q = r * Lg + p;
+            a.run_bidx[0][q] = -1;
+            a.run_bidx[1][q] = -1;
+            a.fin_bidx[0][q] = -1;
+            a.fin_bidx[1][q] = -1;
+        }
+        if (p == 0) {
+            const float rs = (r % a.K == 0) ? 0.0f : -1.0e9f;
+            a.run_score[0][r] = rs;
+            a.run_score[1][r] = rs;
+            a.fin_score[0][r] = -1.0e9f;
+            a.fin_score[1][r] = -1.0e9f;
+            a.fin_done[0][r] = 0;
+            a.fin_done[1][r] = 0;
+            if (r % a.K == 0) a.unsat[r / a.K] = 1;
+        }
+    }
+}
+
+extern "C" int grx_beam_init(const grx_beam_init_args* args, void* stream) {
+    const char* who = "grx_beam_init";
+    GRX_REQUIRE(args != nullptr, GRX_E_INVALID, "%s: null args", who);
+    const grx_beam_init_args& a = *args;
+    GRX_REQUIRE(a.B >= 0 && a.K >= 1 && a.prompt_len >= 0 && a.max_length > a.prompt_len, GRX_E_INVALID,
+                "%s: bad shape", who);
+    if (a.B == 0) return GRX_OK;
+    GRX_REQUIRE(a.ids_stride >= a.prompt_len && (a.prompt_len == 0 || a.input_ids), GRX_E_INVALID,
+                "%s: bad input_ids", who);
+    for (int h = 0; h < 2; ++h)
+        GRX_REQUIRE(a.run_seq[h] && a.fin_seq[h] && a.run_score[h] && a.fin_score[h] && a.run_bidx[h] &&
+                        a.fin_bidx[h] && a.fin_done[h],
+                    GRX_E_INVALID, "%s: null buffer", who);
+    GRX_REQUIRE(a.unsat != nullptr, GRX_E_INVALID, "%s: null unsat", who);
+    const int64_t total = (int64_t)a.B * a.K * a.max_length;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(beam_init_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
     GRX_CHECK_HIP(hipGetLastError());
     return GRX_OK;
 }

@@ -40,23 +40,27 @@ struct grx_trie {
     int device;
 };
 
-// Device words behind grx_state.
+// Device words behind grx_state.  The counter and the "a row ended in
+// prefix_ids" marker are kept in a ring of three slots indexed by the call
+// number: a call reads the previous slot, owns the current one, and re-arms the
+// next one, so no kernel ever resets a word another kernel of the same call reads.
 struct grx_state_words {
-    int32_t count;            // shared step counter of the count-based processor
-    int32_t first_match;      // lowest row whose tail equals prefix_ids in the current call
-    uint32_t err;             // 0xFFFFFFFF = none, else (row << 2) | GRX_ROWERR_*
-    int32_t calls;            // number of processor calls finished
+    int32_t count[3];        // window count in force at the start of the call that owns the slot
+    int32_t first_match[3];  // lowest row whose tail equals prefix_ids in that call, or GRX_NO_MATCH
+    uint32_t err;            // 0xFFFFFFFF = none, else (row << 2) | GRX_ROWERR_*
+    int32_t pad;
 };
 
 struct grx_state {
     grx_state_words* dev;
     int device;
+    uint32_t calls;          // count-based calls issued so far (host side, stream order)
 };
 
 #define GRX_NO_MATCH 0x7FFFFFFF
 #define GRX_NO_ERR 0xFFFFFFFFu
 
-// Row resolution results stored in the workspace (int32 per row).
+// Row resolution results.
 #define GRX_RES_EMPTY (-1)    // trie.get(...) == []            -> GRX_ROWERR_EMPTY
 #define GRX_RES_EOS (-2)      // row ends in EOS                -> allowed = {eos}
 #define GRX_RES_NOMATCH (-3)  // no valid prefix occurrence     -> GRX_ROWERR_NOMATCH
@@ -135,4 +139,39 @@ __device__ __forceinline__ float ordered_to_float(uint32_t o) {
 
 __device__ __forceinline__ void report_row_error(grx_state_words* st, int row, int code) {
     if (st) atomicMin(&st->err, ((uint32_t)row << 2) | (uint32_t)code);
+}
+
+// Count the reference's shared counter holds after the call that owns `slot`:
+// reset to 0 if some row ended in prefix_ids, then incremented once.
+__device__ __host__ __forceinline__ int state_count_after(const grx_state_words& w, int slot) {
+    return (w.first_match[slot] != GRX_NO_MATCH ? 0 : w.count[slot]) + 1;
+}
+
+struct PrefixArg {
+    int32_t n;  // -1 = None
+    int64_t ids[GRX_MAX_PREFIX];
+};
+
+// Fixed-hint resolution of one row by one full wave (fixed_hint_logit_processor.py:18-61):
+// 64 start positions are tested for the prefix at a time and the occurrences are tried
+// left to right until one continues inside the trie.  Returns a node id or GRX_RES_*.
+__device__ __forceinline__ int resolve_fixed_row(const TrieView& tv, const int64_t* __restrict__ row, int T,
+                                                 const PrefixArg& pfx, int eos, int lane) {
+    if (eos >= 0 && T > 0 && row[T - 1] == (int64_t)eos) return GRX_RES_EOS;
+    if (pfx.n <= 0) return trie_walk(tv, row, T);  // start = 0 when prefix_ids is empty or None
+    const int n = pfx.n;
+    for (int base = 0; base + n <= T; base += GRX_WAVE) {
+        const int s = base + lane;
+        bool m = s + n <= T;
+        for (int i = 0; m && i < n; ++i) m = row[s + i] == pfx.ids[i];
+        unsigned long long mask = __ballot(m);
+        while (mask) {
+            const int b = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            const int start = base + b;
+            const int node = trie_walk(tv, row + start, T - start);
+            if (node >= 0) return node;
+        }
+    }
+    return GRX_RES_NOMATCH;
 }

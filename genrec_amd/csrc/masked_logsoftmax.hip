@@ -11,10 +11,17 @@
 #include "common.h"
 #include "resolve.h"
 
+#ifndef MLS_THREADS
 #define MLS_THREADS 256
+#endif
 #define MLS_WAVES (MLS_THREADS / GRX_WAVE)
+#ifndef MLS_UNROLL
 #define MLS_UNROLL 4      // 16-byte loads in flight per thread
-#define MLS_EARLY 2       // allowed tokens gathered per thread before the stream
+#endif
+#ifndef MLS_NT
+#define MLS_NT 1          // 1: non-temporal loads for the logit stream (each byte is read once)
+#endif
+#define MLS_EARLY (512 / MLS_THREADS > 0 ? 512 / MLS_THREADS : 1)  // allowed tokens gathered per thread up front
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
@@ -23,7 +30,13 @@ enum { OUT_COMPACT = 0, OUT_FULL_F32 = 1, OUT_FULL_SAME = 2 };
 struct MlsArgs {
     TrieView tv;
     grx_state_words* st;   // may be null (fixed-hint without error reporting)
-    const int32_t* res;    // [2R] resolution results
+    int slot;              // state slot this call owns (count mode)
+    int mode;              // GRX_MODE_*
+    int prefix_index;
+    PrefixArg pfx;
+    const int64_t* ids;    // [R, T] token rows
+    int64_t ids_stride;
+    int T;
     int R;
     const void* scores;
     int64_t scores_stride;
@@ -40,6 +53,34 @@ struct MlsArgs {
 static constexpr float kLog2e = 1.4426950408889634f;
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+#ifndef MLS_BUF
+#define MLS_BUF 0         // 1: raw buffer loads with cache-policy bits MLS_AUX
+#endif
+#ifndef MLS_AUX
+#define MLS_AUX 0
+#endif
+
+struct RowStream {
+    const u32x4* p;
+#if MLS_BUF
+    __amdgpu_buffer_rsrc_t rsrc;
+#endif
+    __device__ __forceinline__ RowStream(const void* row, int64_t bytes) : p(reinterpret_cast<const u32x4*>(row)) {
+#if MLS_BUF
+        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(row), 0, (int)bytes, 0x00020000);
+#endif
+    }
+    __device__ __forceinline__ u32x4 load(int i) const {
+#if MLS_BUF
+        return __builtin_amdgcn_raw_buffer_load_b128(rsrc, i * 16, 0, MLS_AUX);
+#elif MLS_NT
+        return __builtin_nontemporal_load(p + i);
+#else
+        return p[i];
+#endif
+    }
+};
 
 // ---- element traits --------------------------------------------------------
 template <int DT> struct Elem;
@@ -154,9 +195,24 @@ __global__ __launch_bounds__(MLS_THREADS) void masked_lsm_kernel(MlsArgs a) {
     const int tid = threadIdx.x;
     const T* __restrict__ row = reinterpret_cast<const T*>(a.scores) + (int64_t)r * a.scores_stride;
 
-    // Which trie node governs this row.
-    const int fm = a.st ? a.st->first_match : GRX_NO_MATCH;
-    const int code = a.res[(r >= fm ? a.R : 0) + r];
+    // Which trie node governs this row.  Every wave resolves it redundantly from
+    // wave-uniform addresses (a handful of cached loads), so the stream below can
+    // start without a workgroup barrier.
+    const int64_t* __restrict__ ids_row = a.ids + (int64_t)r * a.ids_stride;
+    int code;
+    if (a.mode == GRX_MODE_COUNT) {
+        const int prev = (a.slot + 2) % 3;
+        int count = state_count_after(*a.st, prev);
+        if (r == 0 && tid == 0) {  // bookkeeping for the next call; no kernel of this call reads these words
+            a.st->count[a.slot] = count;
+            a.st->first_match[(a.slot + 1) % 3] = GRX_NO_MATCH;
+        }
+        if (a.pfx.n >= 0 && r >= a.st->first_match[a.slot]) count = 0;  // the shared counter was reset at or before this row
+        const int start = py_tail_start(a.prefix_index + count, a.T);
+        code = trie_walk(a.tv, ids_row + start, a.T - start);
+    } else {
+        code = resolve_fixed_row(a.tv, ids_row, a.T, a.pfx, a.eos, tid & (GRX_WAVE - 1));
+    }
     int c_off = 0, c_n = 0;
     if (code >= 0) {
         c_off = a.tv.off[code];
@@ -192,7 +248,7 @@ __global__ __launch_bounds__(MLS_THREADS) void masked_lsm_kernel(MlsArgs a) {
     const int nvec = a.V / EPV;
 
     if (VEC) {
-        const u32x4* __restrict__ vp = reinterpret_cast<const u32x4*>(row);
+        const RowStream vp(row, (int64_t)nvec * 16);
         u32x4* __restrict__ op = nullptr;
         if (OUT != OUT_COMPACT) {
             const size_t osz = (OUT == OUT_FULL_F32) ? sizeof(float) : sizeof(T);
@@ -207,7 +263,7 @@ __global__ __launch_bounds__(MLS_THREADS) void masked_lsm_kernel(MlsArgs a) {
         for (; i + (MLS_UNROLL - 1) * MLS_THREADS < nvec; i += MLS_UNROLL * MLS_THREADS) {
             u32x4 v[MLS_UNROLL];
 #pragma unroll
-            for (int u = 0; u < MLS_UNROLL; ++u) v[u] = vp[i + u * MLS_THREADS];
+            for (int u = 0; u < MLS_UNROLL; ++u) v[u] = vp.load(i + u * MLS_THREADS);
             if (OUT != OUT_COMPACT) {
 #pragma unroll
                 for (int u = 0; u < MLS_UNROLL; ++u)
@@ -220,7 +276,7 @@ __global__ __launch_bounds__(MLS_THREADS) void masked_lsm_kernel(MlsArgs a) {
             accumulate<MLS_UNROLL * E::kPerVec>(acc, f);
         }
         for (; i < nvec; i += MLS_THREADS) {
-            const u32x4 v = vp[i];
+            const u32x4 v = vp.load(i);
             if (OUT != OUT_COMPACT) {
 #pragma unroll
                 for (int o = 0; o < OPV; ++o) op[(int64_t)i * OPV + o] = fill;
@@ -349,15 +405,21 @@ static int run_step(const char* who, const grx_trie* trie, grx_state* state, con
     if (rc != GRX_OK) return rc;
     GRX_REQUIRE(con->eos_token_id < rows->V, GRX_E_INVALID, "%s: eos_token_id %d outside V=%d", who,
                 con->eos_token_id, rows->V);
-    if (rows->R == 0) return grx_state_advance(state, con->mode == GRX_MODE_COUNT, stream);
-
-    int32_t* res = reinterpret_cast<int32_t*>(workspace);
-    rc = grx_resolve_rows(trie, state, rows, con, res, stream);
-    if (rc != GRX_OK) return rc;
+    a.slot = 0;
+    if (con->mode == GRX_MODE_COUNT) {
+        rc = grx_begin_count_call(state, rows, con, stream, &a.slot);
+        if (rc != GRX_OK) return rc;
+    }
+    if (rows->R == 0) return GRX_OK;
 
     a.tv = TrieView{trie->child_off, trie->child_tok};
     a.st = state ? state->dev : nullptr;
-    a.res = res;
+    a.mode = con->mode;
+    a.prefix_index = con->prefix_index;
+    a.pfx = grx_prefix_arg(con);
+    a.ids = rows->input_ids;
+    a.ids_stride = rows->ids_stride;
+    a.T = rows->T;
     a.R = rows->R;
     a.scores = rows->scores;
     a.scores_stride = rows->scores_stride;
@@ -374,7 +436,7 @@ static int run_step(const char* who, const grx_trie* trie, grx_state* state, con
         GRX_CHECK_HIP(hipEventRecord(g_ev_stop[slot], stream));
         g_timing_n = slot + 1;
     }
-    return grx_state_advance(state, con->mode == GRX_MODE_COUNT, stream);
+    return GRX_OK;
 }
 
 extern "C" int grx_constrained_logsoftmax(const grx_trie* trie, grx_state* state, const grx_rows* rows,

@@ -3,14 +3,14 @@
 
 #include "common.h"
 
-// Fill res[0..R) / res[R..2R) (device int32) with the trie node whose children
-// are the allowed tokens of each row, or a negative GRX_RES_* code.
-int grx_resolve_rows(const grx_trie* trie, grx_state* state, const grx_rows* rows, const grx_constraint* con,
-                     int32_t* res, hipStream_t stream);
+PrefixArg grx_prefix_arg(const grx_constraint* con);
 
-// Close a processor call: count <- (a row matched prefix_ids ? 0 : count) + 1
-// when bump_count, and re-arm first_match.
-int grx_state_advance(grx_state* state, int bump_count, hipStream_t stream);
+// Open a count-based processor call on `stream`: picks the state slot the call
+// owns, enqueues the scan for rows that end in prefix_ids (when prefix_ids is
+// given) and advances the host-side call counter.  With no rows it only moves
+// the counter forward.
+int grx_begin_count_call(grx_state* state, const grx_rows* rows, const grx_constraint* con, hipStream_t stream,
+                         int* slot_out);
 
 int grx_check_step_args(const char* who, const grx_trie* trie, const grx_state* state, const grx_rows* rows,
                         const grx_constraint* con, const void* workspace, size_t workspace_bytes);

@@ -9,55 +9,122 @@
 #define SC_THREADS 256
 
 // ------------------------------------------------------------- rewards ---
-// One thread per prompt group of K consecutive rows.
-__global__ void sid_rewards_kernel(const int32_t* __restrict__ pred, const int32_t* __restrict__ pred_len, int Lp,
-                                   const int32_t* __restrict__ gt, const int32_t* __restrict__ gt_len, int Lg, int R,
-                                   int K, int prefix_normalize, const float* __restrict__ ndcg_w,
-                                   float* __restrict__ rule_out, float* __restrict__ prefix_out,
-                                   float* __restrict__ ndcg_out) {
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    const int r0 = g * K;
-    if (r0 >= R) return;
-    const int r1 = (r0 + K < R) ? r0 + K : R;
-    bool any_exact = false;
-    for (int r = r0; r < r1; ++r) {
-        const int np = pred_len[r], ng = gt_len[r];
-        const int32_t* p = pred + (int64_t)r * Lp;
-        const int32_t* q = gt + (int64_t)r * Lg;
-        const int n = np < ng ? np : ng;
-        int matched = 0;
-        while (matched < n && p[matched] == q[matched]) ++matched;
-        const bool exact = (np == ng) && (matched == n);
-        any_exact = any_exact || exact;
-        if (rule_out) rule_out[r] = exact ? 1.0f : 0.0f;
-        if (prefix_out) {
-            float v = 0.0f;
-            if (ng > 0) v = prefix_normalize ? (float)((double)matched / (double)ng) : (float)matched;
-            prefix_out[r] = v;
+// One thread per row; a workgroup holds whole prompt groups (K consecutive rows)
+// so that "does the group contain an exact row" is an LDS lookup.
+struct RewardArgs {
+    const void* pred; const int32_t* pred_len; int Lp; int64_t pred_stride;
+    const void* gt; const int32_t* gt_len; int Lg; int64_t gt_stride;
+    const int32_t* table; int table_size;
+    int R, K, rows_per_block, prefix_normalize;
+    const float* ndcg_w;
+    float* rule_out; float* prefix_out; float* ndcg_out; int out_stride;
+};
+
+// WIDE: rows are int64 token ids mapped through the code table; otherwise int32 codes.
+template <bool WIDE>
+__device__ __forceinline__ int sid_code(const RewardArgs& a, const void* row, int i) {
+    if (!WIDE) return static_cast<const int32_t*>(row)[i];
+    const int64_t v = static_cast<const int64_t*>(row)[i];
+    return (v >= 0 && v < a.table_size) ? a.table[v] : -1;
+}
+
+template <bool WIDE>
+__global__ __launch_bounds__(SC_THREADS) void sid_rewards_kernel(RewardArgs a) {
+    __shared__ unsigned char s_exact[SC_THREADS];
+    const int t = threadIdx.x;
+    const int r = blockIdx.x * a.rows_per_block + t;
+    const bool active = t < a.rows_per_block && r < a.R;
+    bool exact = false;
+    int matched = 0, ng = 0;
+    if (active) {
+        const size_t esz = WIDE ? sizeof(int64_t) : sizeof(int32_t);
+        const void* p = static_cast<const char*>(a.pred) + (int64_t)r * a.pred_stride * esz;
+        const void* q = static_cast<const char*>(a.gt) + (int64_t)r * a.gt_stride * esz;
+        const int lp = a.pred_len ? a.pred_len[r] : a.Lp;
+        const int lg = a.gt_len ? a.gt_len[r] : a.Lg;
+        int i = 0, j = 0, np = 0;
+        bool open = true;  // still inside the common prefix
+        while (true) {
+            int cp = -1, cg = -1;
+            // token rows: entries without a code (EOS, padding) are skipped
+            while (i < lp && (cp = sid_code<WIDE>(a, p, i)) < 0 && WIDE) ++i;
+            while (j < lg && (cg = sid_code<WIDE>(a, q, j)) < 0 && WIDE) ++j;
+            const bool hp = i < lp, hg = j < lg;
+            if (!hp && !hg) break;
+            np += hp ? 1 : 0;
+            ng += hg ? 1 : 0;
+            if (hp && hg && open && cp == cg) ++matched; else open = false;
+            i += hp ? 1 : 0;
+            j += hg ? 1 : 0;
         }
-        // provisional NDCG value; zeroed below if the group has no exact row
-        if (ndcg_out && r1 - r0 == K) ndcg_out[r] = exact ? 0.0f : ndcg_w[r - r0];
+        exact = (np == ng) && (matched == np);
     }
-    if (ndcg_out && r1 - r0 == K && !any_exact) {
-        for (int r = r0; r < r1; ++r) ndcg_out[r] = 0.0f;
+    s_exact[t] = exact ? 1 : 0;
+    __syncthreads();
+    if (!active) return;
+    const int64_t o = (int64_t)r * a.out_stride;
+    if (a.rule_out) a.rule_out[o] = exact ? 1.0f : 0.0f;
+    if (a.prefix_out) {
+        float v = 0.0f;
+        if (ng > 0) v = a.prefix_normalize ? (float)((double)matched / (double)ng) : (float)matched;
+        a.prefix_out[o] = v;
     }
+    if (a.ndcg_out) {
+        const int g0 = (t / a.K) * a.K;              // first row of the group inside the block
+        const int64_t r0 = (int64_t)blockIdx.x * a.rows_per_block + g0;
+        if (r0 + a.K <= a.R) {                      // rows of an incomplete trailing group get no value
+            bool any = false;
+            for (int k = 0; k < a.K; ++k) any = any || s_exact[g0 + k];
+            a.ndcg_out[o] = (any && !exact) ? a.ndcg_w[t - g0] : 0.0f;
+        }
+    }
+}
+
+static int launch_rewards(const char* who, RewardArgs& a, bool wide, void* stream) {
+    GRX_REQUIRE(a.R >= 0 && a.K >= 1 && a.Lp >= 0 && a.Lg >= 0 && a.out_stride >= 1, GRX_E_INVALID, "%s: bad shape",
+                who);
+    GRX_REQUIRE(a.K <= SC_THREADS, GRX_E_UNSUPPORTED, "%s: at most %d rows per group", who, SC_THREADS);
+    if (a.R == 0) return GRX_OK;
+    GRX_REQUIRE((a.Lp == 0 || a.pred) && (a.Lg == 0 || a.gt), GRX_E_INVALID, "%s: null input", who);
+    GRX_REQUIRE(a.pred_stride >= a.Lp && a.gt_stride >= a.Lg, GRX_E_INVALID, "%s: row stride smaller than the row",
+                who);
+    GRX_REQUIRE(a.ndcg_out == nullptr || a.ndcg_w != nullptr, GRX_E_INVALID, "%s: ndcg_out needs ndcg_weights", who);
+    a.rows_per_block = (SC_THREADS / a.K) * a.K;
+    const int blocks = (a.R + a.rows_per_block - 1) / a.rows_per_block;
+    if (wide)
+        hipLaunchKernelGGL(sid_rewards_kernel<true>, dim3(blocks), dim3(SC_THREADS), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(sid_rewards_kernel<false>, dim3(blocks), dim3(SC_THREADS), 0, (hipStream_t)stream, a);
+    GRX_CHECK_HIP(hipGetLastError());
+    return GRX_OK;
 }
 
 extern "C" int grx_sid_rewards(const int32_t* pred, const int32_t* pred_len, int32_t Lp, const int32_t* gt,
                                const int32_t* gt_len, int32_t Lg, int32_t R, int32_t K, int32_t prefix_normalize,
                                const float* ndcg_weights, float* rule_out, float* prefix_out, float* ndcg_out,
-                               void* stream) {
-    const char* who = "grx_sid_rewards";
-    GRX_REQUIRE(R >= 0 && K >= 1 && Lp >= 0 && Lg >= 0, GRX_E_INVALID, "%s: bad shape", who);
-    if (R == 0) return GRX_OK;
-    GRX_REQUIRE(pred_len && gt_len && (Lp == 0 || pred) && (Lg == 0 || gt), GRX_E_INVALID, "%s: null input", who);
-    GRX_REQUIRE(ndcg_out == nullptr || ndcg_weights != nullptr, GRX_E_INVALID, "%s: ndcg_out needs ndcg_weights", who);
-    const int groups = (R + K - 1) / K;
-    hipLaunchKernelGGL(sid_rewards_kernel, dim3((groups + SC_THREADS - 1) / SC_THREADS), dim3(SC_THREADS), 0,
-                       (hipStream_t)stream, pred, pred_len, Lp, gt, gt_len, Lg, R, K, prefix_normalize, ndcg_weights,
-                       rule_out, prefix_out, ndcg_out);
-    GRX_CHECK_HIP(hipGetLastError());
-    return GRX_OK;
+                               int32_t out_stride, void* stream) {
+    RewardArgs a;
+    a.pred = pred; a.pred_len = pred_len; a.Lp = Lp; a.pred_stride = Lp;
+    a.gt = gt; a.gt_len = gt_len; a.Lg = Lg; a.gt_stride = Lg;
+    a.table = nullptr; a.table_size = 0;
+    a.R = R; a.K = K; a.prefix_normalize = prefix_normalize; a.ndcg_w = ndcg_weights;
+    a.rule_out = rule_out; a.prefix_out = prefix_out; a.ndcg_out = ndcg_out; a.out_stride = out_stride;
+    return launch_rewards("grx_sid_rewards", a, false, stream);
+}
+
+extern "C" int grx_sid_rewards_tokens(const int64_t* pred_tok, int64_t pred_stride, int32_t Lp, const int64_t* gt_tok,
+                                      int64_t gt_stride, int32_t Lg, const int32_t* code_table, int32_t table_size,
+                                      int32_t R, int32_t K, int32_t prefix_normalize, const float* ndcg_weights,
+                                      float* rule_out, float* prefix_out, float* ndcg_out, int32_t out_stride,
+                                      void* stream) {
+    GRX_REQUIRE(code_table != nullptr && table_size > 0, GRX_E_INVALID, "grx_sid_rewards_tokens: empty code table");
+    RewardArgs a;
+    a.pred = pred_tok; a.pred_len = nullptr; a.Lp = Lp; a.pred_stride = pred_stride;
+    a.gt = gt_tok; a.gt_len = nullptr; a.Lg = Lg; a.gt_stride = gt_stride;
+    a.table = code_table; a.table_size = table_size;
+    a.R = R; a.K = K; a.prefix_normalize = prefix_normalize; a.ndcg_w = ndcg_weights;
+    a.rule_out = rule_out; a.prefix_out = prefix_out; a.ndcg_out = ndcg_out; a.out_stride = out_stride;
+    return launch_rewards("grx_sid_rewards_tokens", a, true, stream);
 }
 
 // ------------------------------------------------------------ hit ranks ---
@@ -115,15 +182,16 @@ __device__ __forceinline__ float weighted_nansum(const float* __restrict__ rpf, 
     return acc;
 }
 
-// One thread per group.  scale: 0 none, 1 group, 2 batch.
+// One thread per row; a workgroup holds whole groups.  scale: 0 none, 1 group, 2 batch.
 __global__ __launch_bounds__(SC_THREADS) void group_advantage_kernel(const float* __restrict__ rpf,
                                                                       const float* __restrict__ w, int R, int n_funcs,
-                                                                      int K, int scale, float eps,
+                                                                      int K, int rows_per_block, int scale, float eps,
                                                                       float* __restrict__ rewards,
                                                                       float* __restrict__ adv,
                                                                       float* __restrict__ gmean,
                                                                       float* __restrict__ gstd) {
     __shared__ double s_tmp[SC_THREADS / GRX_WAVE];
+    __shared__ float s_rew[SC_THREADS];
     float batch_std = 0.0f;
     if (scale == 2) {
         // every workgroup recomputes the unbiased std of all R rewards (R is small)
@@ -137,29 +205,31 @@ __global__ __launch_bounds__(SC_THREADS) void group_advantage_kernel(const float
         }
         batch_std = (float)sqrt(block_sum_f64(q, s_tmp) / (double)(R - 1));
     }
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    const int r0 = g * K;
-    if (r0 >= R) return;
+    const int t = threadIdx.x;
+    const int r = blockIdx.x * rows_per_block + t;
+    const bool active = t < rows_per_block && r < R;
+    const float rew = active ? weighted_nansum(rpf, w, r, n_funcs) : 0.0f;
+    s_rew[t] = rew;
+    __syncthreads();
+    if (!active) return;
+    const int g0 = (t / K) * K;
     double s = 0.0;
-    for (int k = 0; k < K; ++k) s += (double)weighted_nansum(rpf, w, r0 + k, n_funcs);
-    const float mean = (float)(s / (double)K);
+    for (int k = 0; k < K; ++k) s += (double)s_rew[g0 + k];
+    const double mean_d = s / (double)K;
     double q = 0.0;
     for (int k = 0; k < K; ++k) {
-        const double dlt = (double)weighted_nansum(rpf, w, r0 + k, n_funcs) - s / (double)K;
+        const double dlt = (double)s_rew[g0 + k] - mean_d;
         q += dlt * dlt;
     }
+    const float mean = (float)mean_d;
     const float gsd = (float)sqrt(q / (double)(K - 1));
     const float sd = (scale == 2) ? batch_std : gsd;
-    for (int k = 0; k < K; ++k) {
-        const int r = r0 + k;
-        const float rew = weighted_nansum(rpf, w, r, n_funcs);
-        float a = rew - mean;
-        if (scale != 0) a = a / (sd + eps);
-        if (rewards) rewards[r] = rew;
-        if (adv) adv[r] = a;
-        if (gmean) gmean[r] = mean;
-        if (gstd) gstd[r] = sd;
-    }
+    float a = rew - mean;
+    if (scale != 0) a = a / (sd + eps);
+    if (rewards) rewards[r] = rew;
+    if (adv) adv[r] = a;
+    if (gmean) gmean[r] = mean;
+    if (gstd) gstd[r] = sd;
 }
 
 extern "C" int grx_group_advantage(const float* rewards_per_func, const float* weights, int32_t R, int32_t n_funcs,
@@ -167,14 +237,15 @@ extern "C" int grx_group_advantage(const float* rewards_per_func, const float* w
                                    float* group_mean, float* group_std, void* stream) {
     const char* who = "grx_group_advantage";
     GRX_REQUIRE(R >= 0 && n_funcs >= 1 && K >= 1, GRX_E_INVALID, "%s: bad shape", who);
+    GRX_REQUIRE(K <= SC_THREADS, GRX_E_UNSUPPORTED, "%s: at most %d rows per group", who, SC_THREADS);
     GRX_REQUIRE(R % K == 0, GRX_E_INVALID, "%s: %d rows do not split into groups of %d", who, R, K);
     GRX_REQUIRE(scale >= 0 && scale <= 2, GRX_E_INVALID, "%s: bad scale %d", who, scale);
     if (R == 0) return GRX_OK;
     GRX_REQUIRE(rewards_per_func && weights, GRX_E_INVALID, "%s: null input", who);
-    const int groups = R / K;
-    hipLaunchKernelGGL(group_advantage_kernel, dim3((groups + SC_THREADS - 1) / SC_THREADS), dim3(SC_THREADS), 0,
-                       (hipStream_t)stream, rewards_per_func, weights, R, n_funcs, K, scale, eps, rewards, advantages,
-                       group_mean, group_std);
+    const int rows_per_block = (SC_THREADS / K) * K;
+    hipLaunchKernelGGL(group_advantage_kernel, dim3((R + rows_per_block - 1) / rows_per_block), dim3(SC_THREADS), 0,
+                       (hipStream_t)stream, rewards_per_func, weights, R, n_funcs, K, rows_per_block, scale, eps,
+                       rewards, advantages, group_mean, group_std);
     GRX_CHECK_HIP(hipGetLastError());
     return GRX_OK;
 }

@@ -80,8 +80,12 @@ extern "C" int32_t grx_trie_max_fanout(const grx_trie* t) { return t ? t->max_fa
 extern "C" int32_t grx_trie_max_token(const grx_trie* t) { return t ? t->max_token : -1; }
 
 // ----------------------------------------------------------------- state ---
-__global__ void state_set_kernel(grx_state_words* st, int set_count, int32_t count, int clear_err) {
-    if (set_count) st->count = count;
+// set_count: make the NEXT call see `count` (its previous slot then reads count - 1, no match).
+__global__ void state_set_kernel(grx_state_words* st, int set_count, int prev_slot, int32_t count, int clear_err) {
+    if (set_count) {
+        st->count[prev_slot] = count - 1;
+        st->first_match[prev_slot] = GRX_NO_MATCH;
+    }
     if (clear_err) st->err = GRX_NO_ERR;
 }
 
@@ -89,10 +93,17 @@ extern "C" int grx_state_create(grx_state** out) {
     GRX_REQUIRE(out != nullptr, GRX_E_INVALID, "grx_state_create: null pointer");
     grx_state* s = new grx_state();
     s->dev = nullptr;
+    s->calls = 0;
     hipError_t e = hipGetDevice(&s->device);
     if (e == hipSuccess) e = hipMalloc((void**)&s->dev, sizeof(grx_state_words));
     if (e == hipSuccess) {
-        grx_state_words init = {0, GRX_NO_MATCH, GRX_NO_ERR, 0};
+        grx_state_words init;
+        for (int i = 0; i < 3; ++i) {
+            init.count[i] = -1;  // count after "call -1" is 0
+            init.first_match[i] = GRX_NO_MATCH;
+        }
+        init.err = GRX_NO_ERR;
+        init.pad = 0;
         e = hipMemcpy(s->dev, &init, sizeof(init), hipMemcpyHostToDevice);
     }
     if (e != hipSuccess) {
@@ -112,16 +123,19 @@ extern "C" int grx_state_destroy(grx_state* s) {
     return GRX_OK;
 }
 
+static inline int prev_slot_of(const grx_state* s) { return (int)((s->calls + 2u) % 3u); }
+
 extern "C" int grx_state_set_count(grx_state* s, int32_t count, void* stream) {
     GRX_REQUIRE(s != nullptr, GRX_E_INVALID, "grx_state_set_count: null state");
-    hipLaunchKernelGGL(state_set_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, s->dev, 1, count, 0);
+    hipLaunchKernelGGL(state_set_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, s->dev, 1, prev_slot_of(s), count,
+                       0);
     GRX_CHECK_HIP(hipGetLastError());
     return GRX_OK;
 }
 
 extern "C" int grx_state_clear_error(grx_state* s, void* stream) {
     GRX_REQUIRE(s != nullptr, GRX_E_INVALID, "grx_state_clear_error: null state");
-    hipLaunchKernelGGL(state_set_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, s->dev, 0, 0, 1);
+    hipLaunchKernelGGL(state_set_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, s->dev, 0, 0, 0, 1);
     GRX_CHECK_HIP(hipGetLastError());
     return GRX_OK;
 }
@@ -131,7 +145,7 @@ extern "C" int grx_state_read(grx_state* s, int32_t out[4], void* stream) {
     grx_state_words w;
     GRX_CHECK_HIP(hipMemcpyAsync(&w, s->dev, sizeof(w), hipMemcpyDeviceToHost, (hipStream_t)stream));
     GRX_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
-    out[0] = w.count;
+    out[0] = state_count_after(w, prev_slot_of(s));
     if (w.err == GRX_NO_ERR) {
         out[1] = GRX_ROWERR_NONE;
         out[2] = -1;
@@ -139,130 +153,60 @@ extern "C" int grx_state_read(grx_state* s, int32_t out[4], void* stream) {
         out[1] = (int32_t)(w.err & 3u);
         out[2] = (int32_t)(w.err >> 2);
     }
-    out[3] = w.calls;
+    out[3] = (int32_t)s->calls;
     return GRX_OK;
 }
 
-// --------------------------------------------------------------- resolve ---
-struct PrefixArg {
-    int32_t n;  // -1 = None
-    int64_t ids[GRX_MAX_PREFIX];
-};
-
-// Count-based window (logit_processor.py:37-42).  One thread per row.  Writes
-// two candidates per row: res[r] for the window prefix_index + count and
-// res[R + r] for the window prefix_index (count reset to 0); the consumer picks
-// the second for rows at or after the first row whose tail equals prefix_ids,
-// which is where the reference's shared counter drops to zero mid-loop.
-__global__ void resolve_count_kernel(TrieView tv, grx_state_words* st, const int64_t* __restrict__ ids,
-                                     int64_t ids_stride, int R, int T, PrefixArg pfx, int prefix_index,
-                                     int32_t* __restrict__ res) {
+// ------------------------------------------------------------ match scan ---
+// Lowest row whose last prefix_index tokens equal prefix_ids
+// (logit_processor.py:39-40): from that row on the shared counter is 0.
+__global__ void match_scan_kernel(grx_state_words* st, int slot, const int64_t* __restrict__ ids, int64_t ids_stride,
+                                  int R, int T, PrefixArg pfx, int prefix_index) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= R) return;
     const int64_t* row = ids + (int64_t)r * ids_stride;
-    const int count = st->count;
-
     const int s0 = py_tail_start(prefix_index, T);
-    int node0 = GRX_RES_EMPTY;
-    if (pfx.n >= 0) {
-        bool match = (T - s0) == pfx.n;
-        for (int i = 0; match && i < pfx.n; ++i) match = row[s0 + i] == pfx.ids[i];
-        if (match) atomicMin(&st->first_match, r);
-        node0 = trie_walk(tv, row + s0, T - s0);
-    }
-    int nodeC;
-    if (count == 0 && pfx.n >= 0) {
-        nodeC = node0;
-    } else {
-        const int sc = py_tail_start(prefix_index + count, T);
-        nodeC = trie_walk(tv, row + sc, T - sc);
-    }
-    res[r] = nodeC;
-    res[R + r] = (pfx.n >= 0) ? node0 : nodeC;
+    bool match = (T - s0) == pfx.n;
+    for (int i = 0; match && i < pfx.n; ++i) match = row[s0 + i] == pfx.ids[i];
+    if (match) atomicMin(&st->first_match[slot], r);
 }
 
-// Fixed-hint resolution (fixed_hint_logit_processor.py:18-61).  One wave per
-// row: 64 start positions are tested for the prefix at a time, and the
-// occurrences are tried left to right until one continues inside the trie.
-__global__ void resolve_fixed_kernel(TrieView tv, const int64_t* __restrict__ ids, int64_t ids_stride, int R,
-                                     int T, PrefixArg pfx, int eos, int32_t* __restrict__ res) {
-    const int lane = threadIdx.x & (GRX_WAVE - 1);
-    const int r = (blockIdx.x * blockDim.x + threadIdx.x) / GRX_WAVE;
-    if (r >= R) return;  // wave-uniform
-    const int64_t* row = ids + (int64_t)r * ids_stride;
-
-    int out;
-    if (eos >= 0 && T > 0 && row[T - 1] == (int64_t)eos) {
-        out = GRX_RES_EOS;
-    } else if (pfx.n <= 0) {
-        out = trie_walk(tv, row, T);  // start = 0 when prefix_ids is empty or None
-    } else {
-        out = GRX_RES_NOMATCH;
-        const int n = pfx.n;
-        for (int base = 0; base + n <= T && out == GRX_RES_NOMATCH; base += GRX_WAVE) {
-            const int s = base + lane;
-            bool m = s + n <= T;
-            for (int i = 0; m && i < n; ++i) m = row[s + i] == pfx.ids[i];
-            unsigned long long mask = __ballot(m);
-            while (mask) {
-                const int b = __ffsll((long long)mask) - 1;
-                mask &= mask - 1;
-                const int start = base + b;
-                const int node = trie_walk(tv, row + start, T - start);
-                if (node >= 0) {
-                    out = node;
-                    break;
-                }
-            }
-        }
-    }
-    if (lane == 0) {
-        res[r] = out;
-        res[R + r] = out;
-    }
-}
-
-__global__ void state_advance_kernel(grx_state_words* st, int bump_count) {
-    if (bump_count) {
-        const int c = (st->first_match != GRX_NO_MATCH) ? 0 : st->count;
-        st->count = c + 1;
-    }
-    st->first_match = GRX_NO_MATCH;
-    st->calls += 1;
+// Bookkeeping of a count-based call that has no rows to process.
+__global__ void state_bookkeeping_kernel(grx_state_words* st, int slot) {
+    const int prev = (slot + 2) % 3, next = (slot + 1) % 3;
+    st->count[slot] = state_count_after(*st, prev);
+    st->first_match[next] = GRX_NO_MATCH;
 }
 
 extern "C" size_t grx_workspace_bytes(int32_t R) {
-    if (R < 0) return 0;
-    return sizeof(int32_t) * 2 * (size_t)R + 256;
+    (void)R;
+    return 256;  // the current kernels keep all per-row state in registers and LDS
 }
 
-int grx_resolve_rows(const grx_trie* trie, grx_state* state, const grx_rows* rows, const grx_constraint* con,
-                     int32_t* res, hipStream_t stream) {
+PrefixArg grx_prefix_arg(const grx_constraint* con) {
     PrefixArg pfx;
     memset(&pfx, 0, sizeof(pfx));
     pfx.n = con->n_prefix < 0 ? -1 : con->n_prefix;
     for (int i = 0; i < pfx.n; ++i) pfx.ids[i] = con->prefix_ids[i];
-    TrieView tv{trie->child_off, trie->child_tok};
-    const int R = rows->R;
-    if (R == 0) return GRX_OK;
-    if (con->mode == GRX_MODE_COUNT) {
-        const int threads = 128;
-        hipLaunchKernelGGL(resolve_count_kernel, dim3((R + threads - 1) / threads), dim3(threads), 0, stream, tv,
-                           state->dev, rows->input_ids, rows->ids_stride, R, rows->T, pfx, con->prefix_index, res);
-    } else {
-        const int threads = 256;  // 4 rows per workgroup
-        const int rows_per_block = threads / GRX_WAVE;
-        hipLaunchKernelGGL(resolve_fixed_kernel, dim3((R + rows_per_block - 1) / rows_per_block), dim3(threads), 0,
-                           stream, tv, rows->input_ids, rows->ids_stride, R, rows->T, pfx, con->eos_token_id, res);
-    }
-    GRX_CHECK_HIP(hipGetLastError());
-    return GRX_OK;
+    return pfx;
 }
 
-int grx_state_advance(grx_state* state, int bump_count, hipStream_t stream) {
-    if (!state) return GRX_OK;
-    hipLaunchKernelGGL(state_advance_kernel, dim3(1), dim3(1), 0, stream, state->dev, bump_count);
-    GRX_CHECK_HIP(hipGetLastError());
+// Open a count-based call: returns its slot and enqueues the prefix match scan.
+int grx_begin_count_call(grx_state* state, const grx_rows* rows, const grx_constraint* con, hipStream_t stream,
+                         int* slot_out) {
+    const int slot = (int)(state->calls % 3u);
+    *slot_out = slot;
+    if (rows->R == 0) {
+        hipLaunchKernelGGL(state_bookkeeping_kernel, dim3(1), dim3(1), 0, stream, state->dev, slot);
+        GRX_CHECK_HIP(hipGetLastError());
+    } else if (con->n_prefix >= 0) {
+        const int threads = 256;
+        hipLaunchKernelGGL(match_scan_kernel, dim3((rows->R + threads - 1) / threads), dim3(threads), 0, stream,
+                           state->dev, slot, rows->input_ids, rows->ids_stride, rows->R, rows->T, grx_prefix_arg(con),
+                           con->prefix_index);
+        GRX_CHECK_HIP(hipGetLastError());
+    }
+    state->calls += 1;
     return GRX_OK;
 }
 
@@ -284,10 +228,8 @@ int grx_check_step_args(const char* who, const grx_trie* trie, const grx_state* 
                     "%s: null input_ids/scores", who);
         GRX_REQUIRE(rows->ids_stride >= rows->T && rows->scores_stride >= rows->V, GRX_E_INVALID,
                     "%s: row stride smaller than the row", who);
-        GRX_REQUIRE(workspace != nullptr && workspace_bytes >= grx_workspace_bytes(rows->R), GRX_E_WORKSPACE,
-                    "%s: workspace of %zu bytes is too small for %d rows (need %zu)", who, workspace_bytes, rows->R,
-                    grx_workspace_bytes(rows->R));
-        GRX_REQUIRE(((uintptr_t)workspace & 3u) == 0, GRX_E_INVALID, "%s: workspace must be 4-byte aligned", who);
+        (void)workspace;  // reserved: the current kernels need no device scratch
+        (void)workspace_bytes;
     }
     GRX_REQUIRE(trie->max_token < rows->V, GRX_E_INVALID,
                 "%s: the trie holds token id %d but rows have only V=%d columns", who, trie->max_token, rows->V);

@@ -83,34 +83,81 @@ def _default_device() -> torch.device:
     return torch.device("cuda", torch.cuda.current_device())
 
 
-def score_code_rows(pred: torch.Tensor, pred_len: torch.Tensor, gt: torch.Tensor, gt_len: torch.Tensor, num_beams: int,
-                    prefix_normalize: bool = True, want=("rule", "prefix", "ndcg"),
-                    ndcg_weights: Optional[torch.Tensor] = None) -> dict[str, torch.Tensor]:
-    """Launch ``grx_sid_rewards`` on int32 code rows that already live on the device."""
-    for t in (pred, pred_len, gt, gt_len):
-        _lib.require_cuda(t, "reward inputs")
-        assert t.dtype == torch.int32 and t.is_contiguous()
-    R = pred.shape[0]
-    dev = pred.device
-    out = {k: torch.empty(R, dtype=torch.float32, device=dev) for k in want}
-    if "ndcg" in out:
-        out["ndcg"].fill_(float("nan"))  # rows of an incomplete trailing group get no value
+def _reward_columns(R: int, want, dev, num_beams: int, out, ndcg_weights):
+    n = len(want)
+    if out is None:
+        out = torch.empty((R, n), dtype=torch.float32, device=dev)
+    assert out.shape == (R, n) and out.dtype == torch.float32 and out.is_contiguous()
+    cols = {k: out[:, i] for i, k in enumerate(want)}
+    if "ndcg" in cols:
+        if R % num_beams:
+            cols["ndcg"].fill_(float("nan"))  # rows of an incomplete trailing group get no value
         if ndcg_weights is None:
             ndcg_weights = torch.tensor(ndcg_rank_weights(num_beams), dtype=torch.float64).to(torch.float32).to(dev)
+    return cols, n, ndcg_weights
+
+
+def score_code_rows(pred: torch.Tensor, pred_len: Optional[torch.Tensor], gt: torch.Tensor,
+                    gt_len: Optional[torch.Tensor], num_beams: int, prefix_normalize: bool = True,
+                    want=("rule", "prefix", "ndcg"), ndcg_weights: Optional[torch.Tensor] = None,
+                    out: Optional[torch.Tensor] = None) -> dict[str, torch.Tensor]:
+    """Launch ``grx_sid_rewards`` on contiguous int32 code rows that live on the device.
+
+    ``out`` (fp32 [R, len(want)]) receives the rewards as columns in ``want``
+    order and is allocated when absent; the returned dict holds its column views.
+    """
+    for t in (pred, gt):
+        _lib.require_cuda(t, "reward inputs")
+        assert t.dtype == torch.int32 and t.is_contiguous() and t.dim() == 2
+    R, dev = pred.shape[0], pred.device
+    cols, n, ndcg_weights = _reward_columns(R, want, dev, num_beams, out, ndcg_weights)
+
+    def ptr(name):
+        return cols[name].data_ptr() if name in cols else None
+
     index = dev.index if dev.index is not None else torch.cuda.current_device()
     with torch.cuda.device(index):
         _lib.check(
             _lib.lib().grx_sid_rewards(
-                pred.data_ptr(), pred_len.data_ptr(), pred.shape[1], gt.data_ptr(), gt_len.data_ptr(), gt.shape[1],
+                pred.data_ptr(), pred_len.data_ptr() if pred_len is not None else None, pred.shape[1],
+                gt.data_ptr(), gt_len.data_ptr() if gt_len is not None else None, gt.shape[1],
                 R, int(num_beams), 1 if prefix_normalize else 0,
                 ndcg_weights.data_ptr() if ndcg_weights is not None else None,
-                out["rule"].data_ptr() if "rule" in out else None,
-                out["prefix"].data_ptr() if "prefix" in out else None,
-                out["ndcg"].data_ptr() if "ndcg" in out else None,
-                _lib.current_stream_ptr(dev),
+                ptr("rule"), ptr("prefix"), ptr("ndcg"), n, _lib.current_stream_ptr(dev),
             )
         )
-    return out
+    return cols
+
+
+def score_token_rows(pred_tok: torch.Tensor, gt_tok: torch.Tensor, code_table: torch.Tensor, num_beams: int,
+                     prefix_normalize: bool = True, want=("rule", "prefix", "ndcg"),
+                     ndcg_weights: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None
+                     ) -> dict[str, torch.Tensor]:
+    """Launch ``grx_sid_rewards_tokens`` on int64 token rows (any row stride) on the device."""
+    for t in (pred_tok, gt_tok):
+        _lib.require_cuda(t, "reward inputs")
+        assert t.dtype == torch.int64 and t.dim() == 2 and (t.shape[1] == 0 or t.stride(1) == 1)
+    assert code_table.dtype == torch.int32 and code_table.is_contiguous()
+    R, dev = pred_tok.shape[0], pred_tok.device
+    cols, n, ndcg_weights = _reward_columns(R, want, dev, num_beams, out, ndcg_weights)
+
+    def ptr(name):
+        return cols[name].data_ptr() if name in cols else None
+
+    def stride(t):
+        return t.stride(0) if t.shape[0] > 1 else max(t.shape[1], 1)
+
+    index = dev.index if dev.index is not None else torch.cuda.current_device()
+    with torch.cuda.device(index):
+        _lib.check(
+            _lib.lib().grx_sid_rewards_tokens(
+                pred_tok.data_ptr(), stride(pred_tok), pred_tok.shape[1], gt_tok.data_ptr(), stride(gt_tok),
+                gt_tok.shape[1], code_table.data_ptr(), code_table.shape[0], R, int(num_beams),
+                1 if prefix_normalize else 0, ndcg_weights.data_ptr() if ndcg_weights is not None else None,
+                ptr("rule"), ptr("prefix"), ptr("ndcg"), n, _lib.current_stream_ptr(dev),
+            )
+        )
+    return cols
 
 
 def _score_texts(completions, reward_kwargs, num_beams: int, prefix_normalize: bool, want) -> dict[str, list[float]]:
@@ -204,20 +251,20 @@ class SidRewardScorer:
             self.device
         )
 
-    def codes(self, token_ids: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
-        """token ids [R, L] -> (codes [R, L] int32 with SID codes packed left, lengths [R])."""
-        ids = token_ids.to(self.device).long().clamp_(0, self.table.shape[0] - 1)
-        codes = self.table[ids]
-        valid = codes >= 0
-        order = torch.argsort((~valid).to(torch.int8), dim=1, stable=True)  # SID codes first, original order kept
-        packed = torch.gather(codes, 1, order)
-        lens = valid.sum(dim=1).to(torch.int32)
-        return packed.contiguous(), lens.contiguous()
-
     def __call__(self, completion_ids: torch.Tensor, gt_ids: torch.Tensor, hint_ids: Optional[torch.Tensor] = None,
-                 want=("rule", "prefix", "ndcg")) -> dict[str, torch.Tensor]:
+                 want=("rule", "prefix", "ndcg"), out: Optional[torch.Tensor] = None) -> dict[str, torch.Tensor]:
+        """Rewards of [R, L] completion token ids against [R, Lg] ground-truth token ids.
+
+        ``hint_ids`` [R, Lh] (oracle hint tokens, padded with non-SID tokens) are
+        prepended to the completion, as the reference prepends ``oracle_hint_text``
+        (ranking_reward.py:25-30).  ``out`` [R, len(want)] fp32 may be supplied to
+        receive the columns (e.g. the trainer's ``rewards_per_func`` block).
+        """
         full = completion_ids if hint_ids is None else torch.cat([hint_ids.to(completion_ids.device), completion_ids], 1)
-        pred, pred_len = self.codes(full)
-        gt, gt_len = self.codes(gt_ids)
-        return score_code_rows(pred, pred_len, gt, gt_len, self.num_beams, self.prefix_normalize, want,
-                               self.ndcg_weights)
+
+        def rows(t):
+            t = t.to(device=self.device, dtype=torch.int64)
+            return t if t.shape[1] == 0 or t.stride(1) == 1 else t.contiguous()
+
+        return score_token_rows(rows(full), rows(gt_ids), self.table, self.num_beams, self.prefix_normalize, want,
+                                self.ndcg_weights, out=out)

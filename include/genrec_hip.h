@@ -122,7 +122,8 @@ typedef struct grx_constraint {
     int64_t prefix_ids[GRX_MAX_PREFIX];
 } grx_constraint;
 
-/* bytes of device scratch the two calls below need for R rows */
+/* bytes of device scratch the two calls below want for R rows (reserved: the
+ * current kernels keep per-row state in registers and LDS and ask for 256) */
 GRX_API size_t grx_workspace_bytes(int32_t R);
 
 /*
@@ -211,25 +212,63 @@ typedef struct grx_beam_step_args {
 
 GRX_API int grx_beam_step(const grx_beam_step_args* args, void* stream);
 
+/*
+ * Initial state of a beam search (generation/utils.py:3316-3351 of transformers
+ * 5.15.0): sequences = prompt + fill, running scores [0, -1e9, ...], finished
+ * scores -1e9, parent trails -1, nothing finished.  Both halves [0] and [1] of
+ * every double buffer used by grx_beam_step are written, so either can be the
+ * first *_in.  input_ids is device [B*K, prompt_len] with row stride ids_stride.
+ */
+typedef struct grx_beam_init_args {
+    int32_t B, K, prompt_len, max_length;
+    int64_t fill_token;
+    const int64_t* input_ids;
+    int64_t ids_stride;
+    int64_t* run_seq[2];
+    int64_t* fin_seq[2];
+    float* run_score[2];
+    float* fin_score[2];
+    int32_t* run_bidx[2];
+    int32_t* fin_bidx[2];
+    uint8_t* fin_done[2];
+    uint8_t* unsat;
+} grx_beam_init_args;
+
+GRX_API int grx_beam_init(const grx_beam_init_args* args, void* stream);
+
 /* ----------------------------------------------------------------- scoring --- */
 
 /*
  * Rule / prefix / NDCG rewards on SID code tuples (the integers the reference
  * extracts with re.findall(r"_(\d+)") -- util.py:133-134).  Replaces
  * rule_reward, prefix_rule_reward and ndcg_rule_reward
- * (rewards/ranking_reward.py:42-110).  pred [R, Lp] and gt [R, Lg] are device
- * int32 code rows with per-row lengths pred_len / gt_len (number of codes
- * parsed from the text; rows are padded to Lp / Lg).  Any of the three
- * outputs may be NULL.  ndcg_weights is device fp32 [K]
- * (-1/log2(i+2) normalised to sum -1, computed by the caller in float64 as
- * ranking_reward.py:83-84 does).  R must be a multiple of K for the NDCG
- * reward; rows beyond the last full group get no NDCG value, as in the
- * reference loop (ranking_reward.py:101-107).
+ * (rewards/ranking_reward.py:42-110).  pred [R, Lp] and gt [R, Lg] are
+ * contiguous device int32 code rows with per-row lengths pred_len / gt_len
+ * (NULL: the full width).  Any of the three outputs may be NULL; output r is
+ * written at out[r * out_stride] (fp32), so the outputs can be columns of one
+ * [R, n_funcs] matrix.  ndcg_weights is device fp32 [K] (-1/log2(i+2)
+ * normalised to sum -1, computed by the caller in float64 as
+ * ranking_reward.py:83-84 does).  Rows beyond the last full group of K get no
+ * NDCG value, as in the reference loop (ranking_reward.py:101-107).  K <= 256.
  */
 GRX_API int grx_sid_rewards(const int32_t* pred, const int32_t* pred_len, int32_t Lp, const int32_t* gt,
-                    const int32_t* gt_len, int32_t Lg, int32_t R, int32_t K, int32_t prefix_normalize,
-                    const float* ndcg_weights, float* rule_out, float* prefix_out, float* ndcg_out,
-                    void* stream);
+                            const int32_t* gt_len, int32_t Lg, int32_t R, int32_t K, int32_t prefix_normalize,
+                            const float* ndcg_weights, float* rule_out, float* prefix_out, float* ndcg_out,
+                            int32_t out_stride, void* stream);
+
+/*
+ * The same rewards straight from token ids: pred_tok / gt_tok are device int64
+ * rows (as generate() returns them) with row strides in elements, and
+ * code_table[token] (device int32 [table_size]) is the SID code of a token,
+ * negative for tokens that carry none (EOS, padding, ordinary text): those are
+ * skipped, like text the regular expression does not match.  Oracle hint
+ * tokens are simply part of the pred row (ranking_reward.py:25-30).
+ */
+GRX_API int grx_sid_rewards_tokens(const int64_t* pred_tok, int64_t pred_stride, int32_t Lp, const int64_t* gt_tok,
+                                   int64_t gt_stride, int32_t Lg, const int32_t* code_table, int32_t table_size,
+                                   int32_t R, int32_t K, int32_t prefix_normalize, const float* ndcg_weights,
+                                   float* rule_out, float* prefix_out, float* ndcg_out, int32_t out_stride,
+                                   void* stream);
 
 /*
  * HR@k / NDCG@k support: rank of the first beam equal to the target

@@ -1,0 +1,170 @@
+"""GPU parity of the fused beam step (through the C ABI) against traces of the
+installed transformers ``generate`` driving the reference processors, and
+against the CPU oracle of that loop."""
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import load_npz
+
+pytestmark = pytest.mark.gpu
+
+LIVE = -1.0e8      # slots below are -1e9 placeholders / -inf fillers (order unspecified in torch.topk)
+SCORE_TOL = 1e-5
+
+
+def _dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda", 0)
+
+
+def _processor(name, fn, K, prefix, eos):
+    from genrec_amd.fixed_hint_logit_processor import FixedHintConstrainedLogitsProcessor
+    from genrec_amd.logit_processor import ConstrainedLogitsProcessor
+
+    cls = FixedHintConstrainedLogitsProcessor if name.startswith("fixed") else ConstrainedLogitsProcessor
+    return cls(fn, K, 3, prefix, eos, sync_errors=True)
+
+
+@pytest.mark.parametrize("case", ["count_k4_lp1", "count_k16_lp0", "count_k16_lp1", "fixed_k8_lp1"])
+def test_fused_loop_reproduces_hf_generate(case):
+    """Raw logits recorded from generate() go through processor.candidates + grx_beam_step;
+    returned sequences / beam_indices are bit-exact and scores within 1e-5 on live beams."""
+    from genrec_amd.beam import constrained_beam_search
+    from genrec_amd.trie import FlatTrie, create_prefix_allowed_tokens_fn
+
+    dev = _dev()
+    data, meta = load_npz("beams.npz")
+    info = meta["cases"][case]
+    K, prefix, eos, pad, V = info["K"], meta["prefix"], meta["eos"], meta["pad"], meta["V"]
+    trie = FlatTrie(data["trie_sequences"].tolist())
+    fn = create_prefix_allowed_tokens_fn(trie, prefix)
+    proc = _processor(case, fn, K, prefix, eos)
+    prompts = torch.from_numpy(data[f"{case}.prompts"]).to(dev)
+    logits = [torch.from_numpy(data[f"{case}.logits.{t}"]).to(dev) for t in range(info["steps"])]
+    want_scores_t = [data[f"{case}.scores.{t}"] for t in range(info["steps"])]
+    seen = []
+
+    def logits_fn(step, flat, next_parent):
+        # the recorded logits are in HF's beam order of that step; parity on the live beams makes it ours too
+        seen.append(flat.clone())
+        return logits[step]
+
+    state, seqs, scores, bidx = constrained_beam_search(
+        logits_fn, proc, prompts, K, info["max_new_tokens"], eos, pad, info["length_penalty"], False
+    )
+    assert len(seen) == info["steps"], "loop length differs from generate()"
+    want_seqs = data[f"{case}.sequences"]
+    want_scores = data[f"{case}.sequences_scores"]
+    want_bidx = data[f"{case}.beam_indices"]
+    scores = scores.cpu().numpy()
+    live = want_scores > LIVE
+    assert np.array_equal(live, scores > LIVE)
+    assert np.array_equal(seqs.cpu().numpy()[live], want_seqs[live])          # item rankings, bit-exact
+    assert np.array_equal(bidx.cpu().numpy()[live], want_bidx[live])          # beam parents, bit-exact
+    assert np.max(np.abs(scores[live] - want_scores[live])) <= SCORE_TOL
+    assert live.sum() >= live.size // 2
+
+
+@pytest.mark.parametrize("case", ["count_k16_lp1", "fixed_k8_lp1"])
+def test_beam_step_matches_oracle_stepwise(case):
+    """Every state tensor after every step equals the CPU oracle's (live slots)."""
+    from oracle.beam import RefBeamSearch
+    from oracle.processors import compact_from_dense
+
+    from genrec_amd.beam import BeamSearchState
+
+    dev = _dev()
+    data, meta = load_npz("beams.npz")
+    info = meta["cases"][case]
+    K, eos, pad, V = info["K"], meta["eos"], meta["pad"], meta["V"]
+    prompts = torch.from_numpy(data[f"{case}.prompts"]).repeat_interleave(K, dim=0)
+    max_len = prompts.shape[1] + info["max_new_tokens"]
+    ref = RefBeamSearch(prompts, K, max_len, eos, pad, info["length_penalty"], False)
+    for shared in (True, False):
+        ref = RefBeamSearch(prompts, K, max_len, eos, pad, info["length_penalty"], False)
+        st = BeamSearchState(prompts.to(dev), K, max_len, eos, pad, info["length_penalty"], False, shared_prompt=shared)
+        for t in range(info["steps"]):
+            dense = torch.from_numpy(data[f"{case}.scores.{t}"])  # processor output recorded from generate()
+            cmax = int((dense > float("-inf")).sum(dim=1).max())
+            cnt, tok, lp = compact_from_dense(dense, cmax)
+            tr = ref.step(dense)
+            res = st.step(cnt.to(dev), tok.to(dev), lp.to(dev), V)
+            live = tr.topk_scores > LIVE
+            assert torch.equal(res.topk_scores.cpu()[live], tr.topk_scores[live])   # same fp32 adds -> bit-exact
+            assert torch.equal(res.topk_token.cpu().long()[live], tr.topk_token[live])
+            assert torch.equal(res.topk_parent.cpu().long()[live], tr.topk_parent[live])
+            assert torch.equal(res.topk_hit.cpu().bool()[live], tr.topk_hit[live])
+            run_live = ref.running_beam_scores > LIVE
+            assert torch.equal(st.running_beam_scores.cpu()[run_live], ref.running_beam_scores[run_live])
+            assert torch.equal(st.running_sequences.cpu()[run_live], ref.running_sequences[run_live])
+            assert torch.equal(res.next_parent.cpu().view(-1, K)[run_live].long(),
+                               tr.next_parent.view(-1, K)[run_live].long())
+            fin_live = ref.beam_scores > LIVE
+            assert torch.equal(st.beam_scores.cpu()[fin_live], ref.beam_scores[fin_live])
+            assert torch.equal(st.sequences.cpu()[fin_live], ref.sequences[fin_live])
+            assert torch.equal(st.beam_indices.cpu()[fin_live], ref.beam_indices[fin_live])
+            assert torch.equal(st.is_sent_finished.cpu()[fin_live], ref.is_sent_finished[fin_live])
+            assert torch.equal(st.unsat.cpu().bool().view(-1, 1), ref.unsat)
+        assert st.has_unfinished() == ref.has_unfinished()
+
+
+def test_beam_step_large_random_against_oracle():
+    """Synthetic candidates at rollout scale (K=16 and K=50, fan-out up to 242): exact top-2K order."""
+    from oracle.beam import RefBeamSearch
+
+    from genrec_amd.beam import BeamSearchState
+
+    dev = _dev()
+    torch.manual_seed(0)
+    for K, B, cmax, V in ((16, 37, 242, 152704), (50, 5, 242, 152704), (16, 9, 700, 200000), (3, 11, 5, 97)):
+        R = B * K
+        prompts = torch.randint(5, 90, (B, 6)).repeat_interleave(K, dim=0)
+        eos = 1
+        ref = RefBeamSearch(prompts, K, 6 + 4, eos, 0, 1.0, False)
+        st = BeamSearchState(prompts.to(dev), K, 6 + 4, eos, 0, 1.0, False, shared_prompt=True)
+        for step in range(3):
+            cnt = torch.randint(1, cmax + 1, (R,), dtype=torch.int32)
+            if step == 2:
+                cnt[::3] = 1
+            tok = torch.zeros((R, cmax), dtype=torch.int32)
+            lp = torch.zeros((R, cmax), dtype=torch.float32)
+            dense = torch.full((R, V), float("-inf"))
+            for r in range(R):
+                n = int(cnt[r])
+                cols = torch.sort(torch.randperm(V - 2)[:n] + 2).values
+                if step == 2 and r % 3 == 0:
+                    cols = torch.tensor([eos])
+                vals = -torch.rand(n) * 20
+                tok[r, :n] = cols.int()
+                lp[r, :n] = vals
+                dense[r, cols] = vals
+            tr = ref.step(dense)
+            res = st.step(cnt.to(dev), tok.to(dev), lp.to(dev), V)
+            live = tr.topk_scores > LIVE
+            assert torch.equal(res.topk_scores.cpu()[live], tr.topk_scores[live])
+            assert torch.equal(res.topk_token.cpu().long()[live], tr.topk_token[live])
+            assert torch.equal(res.topk_parent.cpu().long()[live], tr.topk_parent[live])
+            run_live = ref.running_beam_scores > LIVE
+            assert torch.equal(st.running_sequences.cpu()[run_live], ref.running_sequences[run_live])
+            fin_live = ref.beam_scores > LIVE
+            assert torch.equal(st.sequences.cpu()[fin_live], ref.sequences[fin_live])
+            assert torch.equal(st.beam_scores.cpu()[fin_live], ref.beam_scores[fin_live])
+
+
+def test_tie_order_is_canonical():
+    """Equal scores are ordered by beam * V + token ascending (documented rule; torch.topk leaves it open)."""
+    from genrec_amd.beam import BeamSearchState
+
+    dev = _dev()
+    K, B, V = 4, 1, 100
+    prompts = torch.zeros((K, 2), dtype=torch.int64, device=dev)
+    st = BeamSearchState(prompts, K, 6, 1, 0, 1.0, False)
+    st.run_score[st.cur].fill_(0.0)  # all beams live with equal score
+    cnt = torch.full((K,), 3, dtype=torch.int32, device=dev)
+    tok = torch.tensor([[10, 20, 30]] * K, dtype=torch.int32, device=dev)
+    lp = torch.full((K, 3), -1.0, device=dev)
+    res = st.step(cnt, tok, lp, V)
+    assert res.topk_parent.cpu().tolist() == [[0, 0, 0, 1, 1, 1, 2, 2]]
+    assert res.topk_token.cpu().tolist() == [[10, 20, 30, 10, 20, 30, 10, 20]]

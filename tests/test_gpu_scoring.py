@@ -1,0 +1,173 @@
+"""GPU parity of rewards, ranking metrics and advantages (through the C ABI)
+against vectors captured from the reference and the reference docs' worked examples."""
+
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import load_json_gz
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda", 0)
+
+
+def test_text_rewards_match_reference_golden():
+    from genrec_amd.rewards import get_ndcg_rule_reward, get_prefix_rule_reward, rule_reward
+
+    _dev()
+    g = load_json_gz("scoring.json.gz")
+    K = g["K"]
+    kw = dict(reward_model=[{"ground_truth": s} for s in g["gts"]], oracle_hint_text=g["hints"])
+    assert rule_reward(None, g["comps"], None, **kw) == g["rule"]
+    assert get_prefix_rule_reward(True)(None, g["comps"], None, **kw) == g["prefix_norm"]
+    assert get_prefix_rule_reward(False)(None, g["comps"], None, **kw) == g["prefix_raw"]
+    got = get_ndcg_rule_reward(K)(None, g["comps"], None, **kw)
+    assert np.allclose(got, g["ndcg"], rtol=0, atol=1e-7) and [x == 0 for x in got] == [x == 0 for x in g["ndcg"]]
+    kw2 = dict(reward_model=[{"ground_truth": s} for s in g["gts2"]])
+    assert rule_reward(None, g["comps2"], None, **kw2) == g["rule2"]
+    assert np.allclose(get_prefix_rule_reward(True)(None, g["comps2"], None, **kw2), g["prefix2"], rtol=0, atol=1e-7)
+    assert np.allclose(get_ndcg_rule_reward(K)(None, g["comps2"], None, **kw2), g["ndcg2"], rtol=0, atol=1e-7)
+    # conversational completions and the positional fallback for reward_model
+    conv = [[{"role": "assistant", "content": c}] for c in g["comps2"]]
+    assert rule_reward(None, conv, None, **kw2) == g["rule2"]
+    assert rule_reward(None, g["comps2"], None, a=1, b=2, rm=kw2["reward_model"], d=4, e=5) == g["rule2"]
+
+
+def test_known_answers_from_reference_tests_and_docs():
+    """tests/test_fixed_hint_runtime.py:143-182 and docs/2026-03-13-genrec-rl-reward-forms.md:119,216-221."""
+    from genrec_amd.rewards import get_ndcg_rule_reward, get_prefix_rule_reward, rule_reward
+    from genrec_amd.rewards.ranking_reward import ndcg_rank_weights
+
+    _dev()
+    gt = "<a_1><b_2><c_3><d_4>"
+    assert rule_reward(["p"], ["<c_3><d_4>"], None, reward_model=[{"ground_truth": gt}],
+                       oracle_hint_text=["<a_1><b_2>"]) == [1.0]
+    assert get_prefix_rule_reward(True)(["p"], ["<c_3><d_9>"], None, reward_model=[{"ground_truth": gt}],
+                                        oracle_hint_text=["<a_1><b_2>"]) == [0.75]
+    r = get_ndcg_rule_reward(2)(["p", "p"], ["<c_3><d_4>", "<c_3><d_9>"], None,
+                                reward_model=[{"ground_truth": gt}] * 2, oracle_hint_text=["<a_1><b_2>"] * 2)
+    assert r[0] == 0.0 and r[1] < 0.0
+    assert [round(w, 4) for w in ndcg_rank_weights(4)] == [-0.3904, -0.2463, -0.1952, -0.1681]
+    gts = ["<a_10><b_20><c_30><d_40>"] * 4
+    comps = ["<a_10><b_20><c_30><d_40>", "<a_10><b_20><c_30><d_99>", "<a_10><b_99><c_88><d_77>",
+             "<a_99><b_88><c_77><d_66>"]
+    kw = dict(reward_model=[{"ground_truth": s} for s in gts])
+    assert rule_reward(None, comps, None, **kw) == [1.0, 0.0, 0.0, 0.0]
+    assert get_prefix_rule_reward(True)(None, comps, None, **kw) == [1.0, 0.75, 0.25, 0.0]
+    assert [round(x, 4) for x in get_ndcg_rule_reward(4)(None, comps, None, **kw)] == [0.0, -0.2463, -0.1952, -0.1681]
+    # a group without an exact row gets all zeros
+    assert get_ndcg_rule_reward(4)(None, comps[1:] + comps[1:2], None, **kw) == [0.0] * 4
+
+
+def test_token_level_scorer_matches_text_rewards():
+    from oracle.scoring import ref_ndcg_reward, ref_prefix_reward, ref_rule_reward
+
+    from genrec_amd.rewards import SidRewardScorer
+    from genrec_amd.synth import EOS_TOKEN_ID, SidTokenizer
+
+    dev = _dev()
+    rng = np.random.default_rng(3)
+    letters = "abcd"
+    toks = [f"<{letters[l]}_{c}>" for l in range(4) for c in range(8)]
+    tk = SidTokenizer(toks)
+    K, groups = 16, 40
+    comps, gts, hints, comp_ids, gt_ids, hint_ids = [], [], [], [], [], []
+    for g in range(groups):
+        gt = rng.integers(0, 8, size=4)
+        d = int(rng.integers(0, 3))
+        for k in range(K):
+            pred = gt.copy() if rng.random() < 0.2 else np.where(rng.random(4) < 0.6, gt, rng.integers(0, 8, size=4))
+            pred[:d] = gt[:d]
+            text = lambda codes, lo, hi: "".join(f"<{letters[i]}_{int(codes[i])}>" for i in range(lo, hi))  # noqa: E731
+            gts.append(text(gt, 0, 4)); hints.append(text(gt, 0, d)); comps.append(text(pred, d, 4))
+            gt_ids.append(tk.encode(gts[-1]))
+            hint_ids.append([tk.pad_token_id] * (2 - d) + tk.encode(hints[-1]))
+            comp_ids.append(tk.encode(comps[-1]) + [EOS_TOKEN_ID] + [tk.pad_token_id] * d)
+    scorer = SidRewardScorer(tk.code_table(), K, dev)
+    res = scorer(torch.tensor(comp_ids, device=dev), torch.tensor(gt_ids, device=dev), torch.tensor(hint_ids, device=dev))
+    assert res["rule"].cpu().tolist() == ref_rule_reward(comps, gts, hints)
+    assert res["prefix"].cpu().tolist() == ref_prefix_reward(comps, gts, hints, True)
+    assert np.allclose(res["ndcg"].cpu().numpy(), ref_ndcg_reward(comps, gts, K, hints), rtol=0, atol=1e-7)
+
+
+def test_metrics_match_reference_golden(tmp_path):
+    from genrec_amd.metrics import compute_metrics, compute_metrics_from_ids
+
+    dev = _dev()
+    g = load_json_gz("scoring.json.gz")
+    save = tmp_path / "run" / "metrics.json"
+    got = compute_metrics(g["metrics_data"], save_path=str(save))
+    assert set(got) == set(g["metrics"])
+    for k, v in g["metrics"].items():
+        assert abs(got[k] - v) <= 1e-12, k
+    import json
+
+    saved = json.loads(save.read_text())
+    assert saved == {k: round(v, 4) for k, v in g["metrics"].items()}
+    assert (tmp_path / "run" / "metrics.tsv").exists()
+    # id-level interface, 50 beams, all cut-offs
+    n, nb, L = 300, 50, 4
+    rng = np.random.default_rng(0)
+    beams = rng.integers(0, 5, size=(n, nb, L))
+    target = rng.integers(0, 5, size=(n, L))
+    m = compute_metrics_from_ids(torch.tensor(beams, device=dev), torch.tensor(target, device=dev))
+    for k in (1, 3, 5, 10, 20, 50):
+        hr, dcg = 0, 0.0
+        for i in range(n):
+            hits = np.nonzero((beams[i] == target[i]).all(axis=1))[0]
+            if len(hits) and hits[0] < k:
+                hr += 1
+                dcg += 1.0 / math.log(hits[0] + 2)
+        assert abs(m[f"HR@{k}"] - hr / n) <= 1e-12
+        assert abs(m[f"NDCG@{k}"] - dcg / n / (1.0 / math.log(2))) <= 1e-12
+    assert compute_metrics([]) == {}
+
+
+def test_group_advantages_match_oracle_and_docs():
+    from oracle.scoring import ref_group_advantage, ref_group_normalize, ref_group_normalize_tokenwise
+
+    from genrec_amd.advantage import group_advantages, group_normalize, group_normalize_tokenwise, ndcg_rank_penalties
+
+    dev = _dev()
+    torch.manual_seed(5)
+    for K, G, F in ((16, 64, 3), (4, 7, 1), (50, 3, 2)):
+        rpf = torch.randn(G * K, F)
+        rpf[3, 0] = float("nan")
+        rpf[::5] = rpf[0]  # some repeated rewards
+        rpf[K : 2 * K] = 1.0  # a zero-variance group
+        w = torch.rand(F)
+        for scale in ("group", "batch", "none"):
+            want = ref_group_advantage(rpf, w, K, scale)
+            got = group_advantages(rpf.to(dev), w.to(dev), K, scale)
+            for a, b, name in zip(got, want, ("rewards", "adv", "mean", "std")):
+                a = a.cpu()
+                tol = 1e-6 * max(1.0, float(b.abs().max()))
+                if name == "adv":
+                    # (r - mean) / (std + 1e-4): in a zero-variance group the reference divides the rounding
+                    # noise of its own fp32 mean (one ulp of the reward) by 1e-4; the kernel forms the mean in
+                    # float64 and returns exactly 0 there, so allow ulp(reward) / 1e-4
+                    tol = 1.2e-7 * max(1.0, float(want[0].abs().max())) / 1e-4 if scale != "none" else 1e-6
+                b = b.expand_as(a) if b.dim() == 0 else b
+                bad = ~torch.isclose(a, b, rtol=1e-5, atol=tol, equal_nan=True)
+                assert not bad.any(), (K, scale, name, a[bad][:4], b[bad][:4], torch.nonzero(bad).flatten()[:4])
+        v = torch.randn(G * K)
+        assert torch.allclose(group_normalize(v.to(dev), K).cpu(), ref_group_normalize(v, K), rtol=1e-5, atol=1e-5)
+        tv = torch.randn(G * K, 7)
+        tm = (torch.rand(G * K, 7) > 0.3).float()
+        tm[:K, 2] = 0  # a position nobody reaches
+        got = group_normalize_tokenwise(tv.to(dev), tm.to(dev), K).cpu()
+        assert torch.allclose(got, ref_group_normalize_tokenwise(tv, tm, K), rtol=1e-5, atol=1e-6)
+    # worked example of docs/2026-03-13-genrec-rl-reward-forms.md:283-301 (prefix_token_only)
+    raw = torch.tensor([[0.25, 0.25, 0.25, 0.25], [0.25, 0.25, 0.25, 0.0], [0.25, 0, 0, 0], [0, 0, 0, 0]])
+    got = group_normalize_tokenwise(raw.to(dev), torch.ones(4, 4, device=dev), 4).cpu()
+    want = torch.tensor([[0.5749, 0.9968, 0.9968, 1.7247], [0.5749, 0.9968, 0.9968, -0.5749],
+                         [0.5749, -0.9968, -0.9968, -0.5749], [-1.7247, -0.9968, -0.9968, -0.5749]])
+    assert torch.allclose(got, want, atol=1e-4)
+    pen = ndcg_rank_penalties(8, 4, dev, process_index=1).cpu()
+    assert [round(float(x), 4) for x in pen] == [-0.3904, -0.2463, -0.1952, -0.1681] * 2
