@@ -86,10 +86,9 @@ class Rollout:
 
         self.args, self.wl, self.device = args, wl, device
         self.R = args.batch * args.beams
-        cmax = max(wl["trie"].max_fanout, 1)
-        self.count = torch.empty(self.R, dtype=torch.int32, device=device)
-        self.tok = torch.empty((self.R, cmax), dtype=torch.int32, device=device)
-        self.logp = torch.empty((self.R, cmax), dtype=torch.float32, device=device)
+        from genrec_amd.logit_processor import Candidates
+
+        self.cand = Candidates(self.R, max(wl["trie"].max_fanout, 1), device)
         self.scorer = SidRewardScorer(wl["tok"].code_table(wl["V"]), args.beams, device)
         self.weights = torch.tensor([1.0, 1.0], dtype=torch.float32, device=device)
         self.rpf = torch.empty((self.R, 2), dtype=torch.float32, device=device)
@@ -118,8 +117,8 @@ class Rollout:
                 self.score()
             self.new_generation()
         flat = self.state.flat_running_sequences()
-        wl["proc"].candidates_into(flat, wl["logits"][self.depth], self.count, self.tok, self.logp)
-        self.state.step(self.count, self.tok, self.logp, wl["V"])
+        wl["proc"].candidates_into(flat, wl["logits"][self.depth], self.cand)
+        self.state.step(self.cand, wl["V"])
         self.depth += 1
 
     def score(self):
@@ -187,6 +186,7 @@ def main() -> None:
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--cpu-groups", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true", help="leave the per-launch HIP events out")
     args = ap.parse_args()
 
     import torch
@@ -218,7 +218,7 @@ def main() -> None:
     torch.cuda.synchronize()
     barrier()
     lib = _lib.lib()
-    lib.grx_timing_enable(1)
+    lib.grx_timing_enable(0 if args.no_kernel_timing else 1)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -241,7 +241,7 @@ def main() -> None:
     if rank == 0:
         R = args.batch * args.beams
         esize = 4 if args.dtype == "fp32" else 2
-        kernel_ms = tot.value / max(n.value, 1)
+        kernel_ms = tot.value / n.value if n.value else float("nan")
         alg_bytes = R * wl["V"] * esize
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
         out = {

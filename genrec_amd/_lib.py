@@ -36,6 +36,7 @@ EXPORTED_SYMBOLS = (
     "grx_workspace_bytes",
     "grx_constrained_logsoftmax",
     "grx_constrained_candidates",
+    "grx_candidate_stride",
     "grx_timing_enable",
     "grx_timing_read",
     "grx_beam_step",
@@ -85,9 +86,8 @@ class GrxBeamStepArgs(C.Structure):
         ("eos_token_id", C.c_int32),
         ("early_stopping", C.c_int32),
         ("length_penalty", C.c_float),
-        ("cand_count", C.c_void_p),
-        ("cand_tok", C.c_void_p),
-        ("cand_logp", C.c_void_p),
+        ("cand", C.c_void_p),
+        ("cand_stride", C.c_int64),
         ("run_seq_in", C.c_void_p),
         ("run_seq_out", C.c_void_p),
         ("run_score_in", C.c_void_p),
@@ -171,8 +171,10 @@ def _declare(lib: C.CDLL) -> None:
     ]
     lib.grx_constrained_candidates.restype = C.c_int
     lib.grx_constrained_candidates.argtypes = [
-        vp, vp, C.POINTER(GrxRows), C.POINTER(GrxConstraint), vp, vp, vp, i32, vp, C.c_size_t, vp,
+        vp, vp, C.POINTER(GrxRows), C.POINTER(GrxConstraint), vp, i64, i32, vp, C.c_size_t, vp,
     ]
+    lib.grx_candidate_stride.restype = i64
+    lib.grx_candidate_stride.argtypes = [i32]
     lib.grx_timing_enable.restype = C.c_int
     lib.grx_timing_enable.argtypes = [C.c_int]
     lib.grx_timing_read.restype = C.c_int

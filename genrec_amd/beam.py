@@ -150,23 +150,20 @@ class BeamSearchState:
             )
         return self._step_out
 
-    def step(self, cand_count: torch.Tensor, cand_tok: torch.Tensor, cand_logp: torch.Tensor, vocab_size: int
-             ) -> BeamStepResult:
-        """Advance by one token from the processor's compact candidates."""
+    def step(self, cand, vocab_size: int) -> BeamStepResult:
+        """Advance by one token from the processor's compact candidates (a ``Candidates`` buffer)."""
         a = _lib.GrxBeamStepArgs()
         i, o = self.cur, 1 - self.cur
         out = self._outputs()
         a.B, a.K, a.V, a.n_keep = self.B, self.K, int(vocab_size), self.n_keep
-        a.cmax = cand_tok.shape[1]
+        a.cmax = cand.cmax
         a.cur_len, a.prompt_len, a.max_length = self.cur_len, self.prompt_len, self.max_length
         a.copy_from = self.copy_from
         a.eos_token_id = -1 if self.eos is None else int(self.eos)
         a.early_stopping = 1 if self.early_stopping is True else (2 if self.early_stopping == "never" else 0)
         a.length_penalty = self.length_penalty
-        assert cand_count.dtype == torch.int32 and cand_tok.dtype == torch.int32 and cand_logp.dtype == torch.float32
-        assert cand_tok.is_contiguous() and cand_logp.is_contiguous() and cand_count.is_contiguous()
-        assert cand_count.shape[0] == self.B * self.K and cand_tok.shape == cand_logp.shape
-        a.cand_count, a.cand_tok, a.cand_logp = cand_count.data_ptr(), cand_tok.data_ptr(), cand_logp.data_ptr()
+        assert cand.rows == self.B * self.K
+        a.cand, a.cand_stride = cand.buf.data_ptr(), cand.stride
         a.run_seq_in, a.run_seq_out = self.run_seq[i].data_ptr(), self.run_seq[o].data_ptr()
         a.run_score_in, a.run_score_out = self.run_score[i].data_ptr(), self.run_score[o].data_ptr()
         a.run_bidx_in, a.run_bidx_out = self.run_bidx[i].data_ptr(), self.run_bidx[o].data_ptr()
@@ -231,12 +228,9 @@ def constrained_beam_search(
     prompts = input_ids.repeat_interleave(num_beams, dim=0)
     state = BeamSearchState(prompts, num_beams, input_ids.shape[1] + max_new_tokens, eos_token_id, pad_token_id,
                             length_penalty, early_stopping, shared_prompt=True)
-    R = state.B * num_beams
-    cmax = max(processor.trie.max_fanout, 1)
-    dev = input_ids.device
-    count = torch.empty(R, dtype=torch.int32, device=dev)
-    tok = torch.empty((R, cmax), dtype=torch.int32, device=dev)
-    logp = torch.empty((R, cmax), dtype=torch.float32, device=dev)
+    from .logit_processor import Candidates
+
+    cand = Candidates(state.B * num_beams, max(processor.trie.max_fanout, 1), input_ids.device)
     if hasattr(processor, "reset"):
         processor.reset()
     step = 0
@@ -244,8 +238,8 @@ def constrained_beam_search(
     while True:
         flat = state.flat_running_sequences()
         logits = logits_fn(step, flat, next_parent)
-        processor.candidates_into(flat, logits, count, tok, logp)
-        res = state.step(count, tok, logp, logits.shape[-1])
+        processor.candidates_into(flat, logits, cand)
+        res = state.step(cand, logits.shape[-1])
         next_parent = res.next_parent
         step += 1
         if max_steps is not None:

@@ -13,28 +13,48 @@
 #define BS_WAVES (BS_THREADS / GRX_WAVE)
 #define BS_MAXK 256
 #define BS_MAXKEEP 512
-#define BS_LDS_KEYS_MAX 8192   // 64 KiB of staged 64-bit keys at most
+#define BS_LDS_KEYS_MAX 16384  // 128 KiB of staged 64-bit keys at most
 #define BS_SURV_CAP 1024       // candidates ranked pairwise after the threshold cut
+#define BS_PREFETCH 16         // beams whose candidate rows are fetched in the opening batch of loads
+#define BS_TAIL_K 64           // beams / positions per row of the sequence tails staged in LDS
+#define BS_TAIL_W 16
 
 struct BeamDerived {
     float fin_div;    // (cur_len + 1 - prompt_len) ** length_penalty
     float heur_div;   // best_hypothetical_length ** length_penalty
     int lds_keys;     // capacity of the dynamic LDS key buffer (0: rescan global memory)
+    int tails_in_lds; // the re-ordered parts of the sequence / parent rows fit the LDS tail buffers
 };
 
-__device__ __forceinline__ unsigned long long make_key(float score, uint32_t flat) {
-    return ((unsigned long long)float_to_ordered(score) << 32) | (unsigned long long)(0xFFFFFFFFu - flat);
+// 64-bit sort key: ordered score in the high word; the low word is the
+// complement of (beam << 24 | token), which orders like beam * V + token.
+__device__ __forceinline__ unsigned long long make_key(float score, uint32_t beam, uint32_t tok) {
+    return ((unsigned long long)float_to_ordered(score) << 32) |
+           (unsigned long long)(0xFFFFFFFFu - ((beam << 24) | tok));
 }
 
 __device__ __forceinline__ bool ranks_before(float va, int ia, float vb, int ib) {
     return va > vb || (va == vb && ia < ib);
 }
 
+#ifdef BS_STAMP
+// Diagnostic build only: per-workgroup phase timestamps (100 MHz counter).
+__device__ unsigned long long g_stamps[1024 * 16];
+#define STAMP(n) do { if (tid == 0 && b < 1024) g_stamps[b * 16 + (n)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+extern "C" __attribute__((visibility("default"))) int grx_debug_read_stamps(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 1024 * 16);
+}
+#else
+#define STAMP(n) do { } while (0)
+#endif
+
+// Layout: the candidates of a group are the K x cmax block behind its first row;
+// slot c = beam * cmax + position holds a key, or 0 when position >= count[beam].
 __global__ __launch_bounds__(BS_THREADS) void beam_step_kernel(grx_beam_step_args a, BeamDerived d) {
     extern __shared__ unsigned long long s_keys[];
-    __shared__ int s_pre[BS_MAXK + 1];
     __shared__ int s_cnt[BS_MAXK];
     __shared__ float s_runin[BS_MAXK];
+    __shared__ unsigned char s_fdone_in[BS_MAXK];
     __shared__ unsigned long long s_tmax[BS_THREADS];
     __shared__ unsigned long long s_surv[BS_SURV_CAP];
     __shared__ int s_nsurv;
@@ -50,43 +70,70 @@ __global__ __launch_bounds__(BS_THREADS) void beam_step_kernel(grx_beam_step_arg
     __shared__ int s_fin_idx[BS_MAXK];
     __shared__ float s_newfin[BS_MAXK];
     __shared__ unsigned char s_newdone[BS_MAXK];
+    __shared__ int64_t s_rseq[BS_TAIL_K * BS_TAIL_W];
+    __shared__ int64_t s_fseq[BS_TAIL_K * BS_TAIL_W];
+    __shared__ int32_t s_rbidx[BS_TAIL_K * BS_TAIL_W];
+    __shared__ int32_t s_fbidx[BS_TAIL_K * BS_TAIL_W];
 
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
     const int lane = tid & (GRX_WAVE - 1);
     const int wave = tid / GRX_WAVE;
-    const int K = a.K, V = a.V, n_keep = a.n_keep, cmax = a.cmax;
+    const int K = a.K, n_keep = a.n_keep, cmax = a.cmax;
     const int64_t row0 = (int64_t)b * K;
+    const int L = a.max_length;
+    const int Lg = a.max_length - a.prompt_len;
+    const int gpos = a.cur_len - a.prompt_len;
+    const int w_run = a.cur_len - a.copy_from;        // positions of a running row that move with a re-order
+    const int w_fin = a.cur_len + 1 - a.copy_from;    // ... of a finished row
+    const int slots = K * cmax;
+    const bool staged = slots <= d.lds_keys;
+    STAMP(0);
 
-    // ---- candidate layout: prefix sums of the per-beam counts
-    for (int k = tid; k < K; k += BS_THREADS) {
-        s_cnt[k] = a.cand_count[row0 + k];
-        s_runin[k] = a.run_score_in[row0 + k];
+    // ---- phase A: every global read the step needs is issued before the first wait.
+    // Thread t prefetches column t of the first BS_PREFETCH beams (coalesced rows).
+    grx_cand pre[BS_PREFETCH];
+    const grx_cand* __restrict__ g_cand = a.cand + row0 * a.cand_stride;
+#pragma unroll
+    for (int u = 0; u < BS_PREFETCH; ++u) {
+        // entries past a beam's count hold stale values; they are masked below
+        pre[u] = g_cand[(u < K && tid < cmax) ? (int64_t)u * a.cand_stride + 1 + tid : 0];
     }
-    __syncthreads();
-    if (tid == 0) {
-        int acc = 0;
-        for (int k = 0; k < K; ++k) {
-            s_pre[k] = acc;
-            acc += s_cnt[k];
+    for (int k = tid; k < K; k += BS_THREADS) {
+        s_cnt[k] = g_cand[(int64_t)k * a.cand_stride].x;
+        s_runin[k] = a.run_score_in[row0 + k];
+        s_fdone_in[k] = a.fin_done_in[row0 + k];
+        s_merged[k] = a.fin_score_in[row0 + k];
+    }
+    const bool unsat_old = a.unsat[b] != 0;
+    if (d.tails_in_lds) {  // K <= BS_TAIL_K rows of at most BS_TAIL_W moving positions: thread = (row, position)
+        const int p = tid & (BS_TAIL_W - 1);
+        for (int k = tid / BS_TAIL_W; k < K; k += BS_THREADS / BS_TAIL_W) {
+            if (p < w_fin) s_fseq[k * BS_TAIL_W + p] = a.fin_seq_in[(row0 + k) * L + a.copy_from + p];
+            if (p < w_run) s_rseq[k * BS_TAIL_W + p] = a.run_seq_in[(row0 + k) * L + a.copy_from + p];
+            if (p < gpos + 1) s_fbidx[k * BS_TAIL_W + p] = a.fin_bidx_in[(row0 + k) * Lg + p];
+            if (p < gpos) s_rbidx[k * BS_TAIL_W + p] = a.run_bidx_in[(row0 + k) * Lg + p];
         }
-        s_pre[K] = acc;
+    }
+    if (tid == 0) {
         s_nsurv = 0;
         s_thresh = 0;
     }
+    STAMP(1);
     __syncthreads();
-    const int N = s_pre[K];
-    const bool staged = N <= d.lds_keys;
+    STAMP(2);
+#if defined(BS_ABLATE) && BS_ABLATE == 1
+    if (tid == 0) a.unsat[b] = (unsigned char)(s_cnt[0] + pre[0].x + pre[1].y + (int)s_fseq[0] + s_rbidx[0]);
+    return;
+#endif
 
-    auto key_of = [&](int c) -> unsigned long long {  // candidate c in flat (beam, position) order
-        int k = 0;  // largest k with s_pre[k] <= c
-#pragma unroll
-        for (int stepk = BS_MAXK / 2; stepk > 0; stepk >>= 1) {
-            const int cand = k + stepk;
-            if (cand < K && s_pre[cand] <= c) k = cand;
-        }
-        const int64_t at = (row0 + k) * cmax + (c - s_pre[k]);
-        return make_key(a.cand_logp[at] + s_runin[k], (uint32_t)k * (uint32_t)V + (uint32_t)a.cand_tok[at]);
+    auto key_at = [&](int k, int i, float lp, int tk) -> unsigned long long {
+        return i < s_cnt[k] ? make_key(lp + s_runin[k], (uint32_t)k, (uint32_t)tk) : 0ull;
+    };
+    auto key_of = [&](int c) -> unsigned long long {  // flat slot c = beam * cmax + position
+        const int k = c / cmax, i = c - k * cmax;
+        const grx_cand e = g_cand[(int64_t)k * a.cand_stride + 1 + i];
+        return key_at(k, i, __int_as_float(e.y), e.x);
     };
     auto emit = [&](int j, unsigned long long key) {
         if (key == 0) {  // fewer candidates than n_keep: a -inf filler slot
@@ -94,10 +141,10 @@ __global__ __launch_bounds__(BS_THREADS) void beam_step_kernel(grx_beam_step_arg
             s_parent[j] = 0;
             s_tok[j] = 0;
         } else {
-            const uint32_t flat = 0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull);
+            const uint32_t packed = 0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull);
             s_score[j] = ordered_to_float((uint32_t)(key >> 32));
-            s_parent[j] = (int)(flat / (uint32_t)V);
-            s_tok[j] = (int)(flat % (uint32_t)V);
+            s_parent[j] = (int)(packed >> 24);
+            s_tok[j] = (int)(packed & 0xFFFFFFu);
         }
     };
 
@@ -107,59 +154,50 @@ __global__ __launch_bounds__(BS_THREADS) void beam_step_kernel(grx_beam_step_arg
     // reach) leaves a few dozen survivors; they are ranked against each other.
     bool selected = false;
     if (staged) {
-        int widest = 0;
-        for (int k = 0; k < K; ++k) widest = s_cnt[k] > widest ? s_cnt[k] : widest;
-        for (int i = tid; i < widest; i += BS_THREADS) {
-            // four beams per batch so that their candidate loads are in flight together
-            for (int k0 = 0; k0 < K; k0 += 4) {
-                float lp[4];
-                int tk[4];
+        // slot layout in LDS: beam-major, s_keys[k * cmax + i]
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int k = k0 + u;
-                    const bool ok = k < K && i < s_cnt[k];
-                    const int64_t at = ok ? (row0 + k) * cmax + i : row0 * cmax;
-                    lp[u] = a.cand_logp[at];
-                    tk[u] = a.cand_tok[at];
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int k = k0 + u;
-                    if (k < K && i < s_cnt[k]) {
-                        const unsigned long long kv =
-                            make_key(lp[u] + s_runin[k], (uint32_t)k * (uint32_t)V + (uint32_t)tk[u]);
-                        s_keys[s_pre[k] + i] = kv;
-                    }
-                }
+        for (int u = 0; u < BS_PREFETCH; ++u) {
+            if (u < K && tid < cmax) s_keys[u * cmax + tid] = key_at(u, tid, __int_as_float(pre[u].y), pre[u].x);
+        }
+        for (int k = 0; k < K; ++k) {  // whatever the opening batch did not cover
+            for (int i = tid + (k < BS_PREFETCH ? BS_THREADS : 0); i < cmax; i += BS_THREADS) {
+                const grx_cand e = g_cand[(int64_t)k * a.cand_stride + 1 + i];
+                s_keys[k * cmax + i] = key_at(k, i, __int_as_float(e.y), e.x);
             }
         }
+        STAMP(3);
         __syncthreads();
-        // per-thread maxima over a strided slice of the staged keys (every thread owns one when N > threads)
-        unsigned long long tmax = 0;
-        for (int c = tid; c < N; c += BS_THREADS) tmax = s_keys[c] > tmax ? s_keys[c] : tmax;
-        const bool prefilter = N > BS_THREADS && n_keep <= BS_THREADS;  // every thread then holds a key
-        if (prefilter) {
-            s_tmax[tid] = tmax;
-            __syncthreads();
+        unsigned long long tmax = 0;  // maximum over a strided slice of the slots
+#pragma unroll 4
+        for (int c = tid; c < slots; c += BS_THREADS) tmax = s_keys[c] > tmax ? s_keys[c] : tmax;
+        s_tmax[tid] = tmax;
+        STAMP(4);
+        __syncthreads();
+        if (tmax != 0) {
             int rank = 0;
+#pragma unroll 16
             for (int j = 0; j < BS_THREADS; ++j) rank += s_tmax[j] > tmax ? 1 : 0;
-            if (rank == n_keep - 1) s_thresh = tmax;
+            if (rank == n_keep - 1) s_thresh = tmax;  // stays 0 when fewer than n_keep threads hold a key
         }
+        STAMP(5);
         __syncthreads();
         const unsigned long long thresh = s_thresh;
-        for (int c = tid; c < N; c += BS_THREADS) {
+#pragma unroll 4
+        for (int c = tid; c < slots; c += BS_THREADS) {
             const unsigned long long kv = s_keys[c];
-            if (kv >= thresh) {
+            if (kv != 0 && kv >= thresh) {
                 const int at = atomicAdd(&s_nsurv, 1);
                 if (at < BS_SURV_CAP) s_surv[at] = kv;
             }
         }
+        STAMP(6);
         __syncthreads();
         const int M = s_nsurv;
         if (M <= BS_SURV_CAP) {
             for (int i = tid; i < M; i += BS_THREADS) {
                 const unsigned long long kv = s_surv[i];
                 int rank = 0;
+#pragma unroll 8
                 for (int j = 0; j < M; ++j) rank += s_surv[j] > kv ? 1 : 0;
                 if (rank < n_keep) emit(rank, kv);
             }
@@ -174,12 +212,12 @@ __global__ __launch_bounds__(BS_THREADS) void beam_step_kernel(grx_beam_step_arg
             unsigned long long best = 0;
             if (prev != 0) {
                 if (staged) {
-                    for (int c = tid; c < N; c += BS_THREADS) {
+                    for (int c = tid; c < slots; c += BS_THREADS) {
                         const unsigned long long kv = s_keys[c];
                         if (kv < prev && kv > best) best = kv;
                     }
                 } else {
-                    for (int c = tid; c < N; c += BS_THREADS) {
+                    for (int c = tid; c < slots; c += BS_THREADS) {
                         const unsigned long long kv = key_of(c);
                         if (kv < prev && kv > best) best = kv;
                     }
@@ -195,14 +233,21 @@ __global__ __launch_bounds__(BS_THREADS) void beam_step_kernel(grx_beam_step_arg
             prev = best;
         }
     }
+    STAMP(7);
     __syncthreads();
+    STAMP(8);
+#if defined(BS_ABLATE) && BS_ABLATE == 2
+    if (tid == 0) a.unsat[b] = (unsigned char)(s_tok[0] + s_parent[1]);
+    return;
+#endif
 
     // ---- stopping criteria and the two masked score vectors
     const bool at_max_len = (a.cur_len + 1) >= a.max_length;
-    bool all_done = true;
-    for (int k = 0; k < K; ++k) all_done = all_done && (a.fin_done_in[row0 + k] != 0);
+    int n_done = 0;
+#pragma unroll 8
+    for (int k = 0; k < K; ++k) n_done += s_fdone_in[k] != 0 ? 1 : 0;
+    const bool all_done = n_done == K;
     const bool beams_full = all_done && (a.early_stopping == 1);
-    const bool unsat_old = a.unsat[b] != 0;
     for (int j = tid; j < n_keep; j += BS_THREADS) {
         const bool hit = at_max_len || (a.eos_token_id >= 0 && s_tok[j] == a.eos_token_id);
         s_hit[j] = hit ? 1 : 0;
@@ -214,13 +259,14 @@ __global__ __launch_bounds__(BS_THREADS) void beam_step_kernel(grx_beam_step_arg
         if (!(hit && j < K)) fs += -1.0e9f;
         s_merged[K + j] = fs;
     }
-    for (int k = tid; k < K; k += BS_THREADS) s_merged[k] = a.fin_score_in[row0 + k];
+    STAMP(9);
     __syncthreads();
 
     // ---- running top-K (of n_keep) and finished top-K (of K + n_keep) by rank counting
     for (int j = tid; j < n_keep; j += BS_THREADS) {
         const float v = s_rs[j];
         int rank = 0;
+#pragma unroll 8
         for (int i = 0; i < n_keep; ++i) rank += ranks_before(s_rs[i], i, v, j) ? 1 : 0;
         if (rank < K) s_run_idx[rank] = j;
     }
@@ -228,10 +274,17 @@ __global__ __launch_bounds__(BS_THREADS) void beam_step_kernel(grx_beam_step_arg
     for (int j = tid; j < n_merged; j += BS_THREADS) {
         const float v = s_merged[j];
         int rank = 0;
+#pragma unroll 8
         for (int i = 0; i < n_merged; ++i) rank += ranks_before(s_merged[i], i, v, j) ? 1 : 0;
         if (rank < K) s_fin_idx[rank] = j;
     }
+    STAMP(10);
     __syncthreads();
+    STAMP(11);
+#if defined(BS_ABLATE) && BS_ABLATE == 3
+    if (tid == 0) a.unsat[b] = (unsigned char)(s_run_idx[0] + s_fin_idx[1]);
+    return;
+#endif
 
     // ---- write the per-step results
     for (int j = tid; j < n_keep; j += BS_THREADS) {
@@ -241,10 +294,6 @@ __global__ __launch_bounds__(BS_THREADS) void beam_step_kernel(grx_beam_step_arg
         if (a.topk_token) a.topk_token[o] = s_tok[j];
         if (a.topk_hit) a.topk_hit[o] = s_hit[j];
     }
-
-    const int L = a.max_length;
-    const int Lg = a.max_length - a.prompt_len;
-    const int gpos = a.cur_len - a.prompt_len;
     for (int k = tid; k < K; k += BS_THREADS) {
         const int j = s_run_idx[k];
         a.run_score_out[row0 + k] = s_rs[j];
@@ -253,14 +302,12 @@ __global__ __launch_bounds__(BS_THREADS) void beam_step_kernel(grx_beam_step_arg
         if (a.next_parent) a.next_parent[row0 + k] = (int)row0 + s_parent[j];
 
         const int m = s_fin_idx[k];
-        float fscore;
+        const float fscore = s_merged[m];
         unsigned char fdone;
         if (m < K) {
-            fscore = s_merged[m];
-            fdone = a.fin_done_in[row0 + m];
+            fdone = s_fdone_in[m];
         } else {
             const int jj = m - K;
-            fscore = s_merged[m];
             fdone = (s_hit[jj] && jj < K) ? 1 : 0;
             a.fin_seq_out[(row0 + k) * L + a.cur_len] = (int64_t)s_tok[jj];
             a.fin_bidx_out[(row0 + k) * Lg + gpos] = (int)row0 + s_parent[jj];
@@ -272,50 +319,72 @@ __global__ __launch_bounds__(BS_THREADS) void beam_step_kernel(grx_beam_step_arg
     }
 
     // sequence bodies [copy_from, cur_len) (+ position cur_len for carried-over finished rows)
-    const int w_run = a.cur_len - a.copy_from;
-    for (int idx = tid; idx < K * w_run; idx += BS_THREADS) {
-        const int k = idx / w_run, p = a.copy_from + idx % w_run;
-        const int src = s_parent[s_run_idx[k]];
-        a.run_seq_out[(row0 + k) * L + p] = a.run_seq_in[(row0 + src) * L + p];
-    }
-    const int w_fin = a.cur_len + 1 - a.copy_from;
-    for (int idx = tid; idx < K * w_fin; idx += BS_THREADS) {
-        const int k = idx / w_fin, p = a.copy_from + idx % w_fin;
-        const int m = s_fin_idx[k];
-        if (m < K) {
-            a.fin_seq_out[(row0 + k) * L + p] = a.fin_seq_in[(row0 + m) * L + p];
-        } else if (p < a.cur_len) {
-            a.fin_seq_out[(row0 + k) * L + p] = a.run_seq_in[(row0 + s_parent[m - K]) * L + p];
+    // and parent trails [0, gpos) (+ position gpos for carried-over finished rows)
+    if (d.tails_in_lds) {
+        const int p = tid & (BS_TAIL_W - 1);
+        for (int k = tid / BS_TAIL_W; k < K; k += BS_THREADS / BS_TAIL_W) {
+            const int rsrc = s_parent[s_run_idx[k]];
+            const int m = s_fin_idx[k];
+            if (p < w_run) a.run_seq_out[(row0 + k) * L + a.copy_from + p] = s_rseq[rsrc * BS_TAIL_W + p];
+            if (p < gpos) a.run_bidx_out[(row0 + k) * Lg + p] = s_rbidx[rsrc * BS_TAIL_W + p];
+            if (m < K) {
+                if (p < w_fin) a.fin_seq_out[(row0 + k) * L + a.copy_from + p] = s_fseq[m * BS_TAIL_W + p];
+                if (p < gpos + 1) a.fin_bidx_out[(row0 + k) * Lg + p] = s_fbidx[m * BS_TAIL_W + p];
+            } else {
+                const int fsrc = s_parent[m - K];
+                if (p < w_run) a.fin_seq_out[(row0 + k) * L + a.copy_from + p] = s_rseq[fsrc * BS_TAIL_W + p];
+                if (p < gpos) a.fin_bidx_out[(row0 + k) * Lg + p] = s_rbidx[fsrc * BS_TAIL_W + p];
+            }
+        }
+    } else {
+        for (int idx = tid; idx < K * w_run; idx += BS_THREADS) {
+            const int k = idx / w_run, p = idx % w_run;
+            const int src = s_parent[s_run_idx[k]];
+            a.run_seq_out[(row0 + k) * L + a.copy_from + p] = a.run_seq_in[(row0 + src) * L + a.copy_from + p];
+        }
+        for (int idx = tid; idx < K * w_fin; idx += BS_THREADS) {
+            const int k = idx / w_fin, p = idx % w_fin;
+            const int m = s_fin_idx[k];
+            const int64_t at = (row0 + k) * L + a.copy_from + p;
+            if (m < K) {
+                a.fin_seq_out[at] = a.fin_seq_in[(row0 + m) * L + a.copy_from + p];
+            } else if (p < w_run) {
+                a.fin_seq_out[at] = a.run_seq_in[(row0 + s_parent[m - K]) * L + a.copy_from + p];
+            }
+        }
+        for (int idx = tid; idx < K * gpos; idx += BS_THREADS) {
+            const int k = idx / gpos, q = idx % gpos;
+            a.run_bidx_out[(row0 + k) * Lg + q] = a.run_bidx_in[(row0 + s_parent[s_run_idx[k]]) * Lg + q];
+        }
+        for (int idx = tid; idx < K * (gpos + 1); idx += BS_THREADS) {
+            const int k = idx / (gpos + 1), q = idx % (gpos + 1);
+            const int m = s_fin_idx[k];
+            if (m < K) {
+                a.fin_bidx_out[(row0 + k) * Lg + q] = a.fin_bidx_in[(row0 + m) * Lg + q];
+            } else if (q < gpos) {
+                a.fin_bidx_out[(row0 + k) * Lg + q] = a.run_bidx_in[(row0 + s_parent[m - K]) * Lg + q];
+            }
         }
     }
-    // parent trails [0, gpos) (+ position gpos for carried-over finished rows)
-    for (int idx = tid; idx < K * gpos; idx += BS_THREADS) {
-        const int k = idx / gpos, q = idx % gpos;
-        a.run_bidx_out[(row0 + k) * Lg + q] = a.run_bidx_in[(row0 + s_parent[s_run_idx[k]]) * Lg + q];
-    }
-    for (int idx = tid; idx < K * (gpos + 1); idx += BS_THREADS) {
-        const int k = idx / (gpos + 1), q = idx % (gpos + 1);
-        const int m = s_fin_idx[k];
-        if (m < K) {
-            a.fin_bidx_out[(row0 + k) * Lg + q] = a.fin_bidx_in[(row0 + m) * Lg + q];
-        } else if (q < gpos) {
-            a.fin_bidx_out[(row0 + k) * Lg + q] = a.run_bidx_in[(row0 + s_parent[m - K]) * Lg + q];
-        }
-    }
+    STAMP(12);
     __syncthreads();
+    STAMP(13);
 
     // ---- early-stop heuristic for the next iteration
     if (tid == 0) {
         const float best_possible = s_rs[s_run_idx[0]] / d.heur_div;
         float worst_all = s_newfin[0];
+#pragma unroll 8
         for (int k = 1; k < K; ++k) worst_all = fminf(worst_all, s_newfin[k]);
         bool any = false;
+#pragma unroll 8
         for (int k = 0; k < K; ++k) {
             const float worst = s_newdone[k] ? worst_all : -1.0e9f;
             any = any || (best_possible > worst);
         }
         a.unsat[b] = (unsat_old && any) ? 1 : 0;
     }
+    STAMP(14);
 }
 
 extern "C" int grx_beam_step(const grx_beam_step_args* args, void* stream) {
@@ -326,13 +395,15 @@ extern "C" int grx_beam_step(const grx_beam_step_args* args, void* stream) {
     GRX_REQUIRE(a.K <= BS_MAXK && a.n_keep <= BS_MAXKEEP, GRX_E_UNSUPPORTED,
                 "%s: supports at most %d beams and %d kept candidates", who, BS_MAXK, BS_MAXKEEP);
     GRX_REQUIRE(a.n_keep >= a.K, GRX_E_INVALID, "%s: n_keep must be >= K", who);
-    GRX_REQUIRE((uint64_t)a.K * (uint64_t)a.V <= 0xFFFFFFFFull, GRX_E_UNSUPPORTED, "%s: K * V exceeds 32 bits", who);
+    GRX_REQUIRE(a.V <= (1 << 24), GRX_E_UNSUPPORTED, "%s: vocabularies above 2^24 tokens are not supported", who);
+    GRX_REQUIRE((int64_t)a.K * a.cmax <= 0x7FFFFFFF, GRX_E_UNSUPPORTED, "%s: K * cmax exceeds 31 bits", who);
     GRX_REQUIRE(a.prompt_len >= 0 && a.cur_len >= a.prompt_len && a.cur_len < a.max_length, GRX_E_INVALID,
                 "%s: need prompt_len <= cur_len < max_length", who);
     GRX_REQUIRE(a.copy_from >= 0 && a.copy_from <= a.cur_len, GRX_E_INVALID, "%s: bad copy_from", who);
     GRX_REQUIRE(a.early_stopping >= 0 && a.early_stopping <= 2, GRX_E_INVALID, "%s: bad early_stopping", who);
+    GRX_REQUIRE(a.cand_stride >= (int64_t)a.cmax + 1, GRX_E_INVALID, "%s: cand_stride smaller than cmax + 1", who);
     if (a.B == 0) return GRX_OK;
-    GRX_REQUIRE(a.cand_count && a.cand_tok && a.cand_logp && a.run_seq_in && a.run_seq_out && a.run_score_in &&
+    GRX_REQUIRE(a.cand && a.run_seq_in && a.run_seq_out && a.run_score_in &&
                     a.run_score_out && a.run_bidx_in && a.run_bidx_out && a.fin_seq_in && a.fin_seq_out &&
                     a.fin_score_in && a.fin_score_out && a.fin_bidx_in && a.fin_bidx_out && a.fin_done_in &&
                     a.fin_done_out && a.unsat,
@@ -348,12 +419,12 @@ extern "C" int grx_beam_step(const grx_beam_step_args* args, void* stream) {
     const int hyp = (a.early_stopping == 2 && a.length_penalty > 0.0f) ? (a.max_length - a.prompt_len)
                                                                        : (a.cur_len + 1 - a.prompt_len);
     d.heur_div = (float)pow((double)hyp, lp);
-    int keys = 1;
-    const int64_t worst = (int64_t)a.K * a.cmax;
-    while (keys < worst && keys < BS_LDS_KEYS_MAX) keys <<= 1;
-    d.lds_keys = keys;
-    const size_t lds_bytes = (size_t)keys * sizeof(unsigned long long);
-    if (lds_bytes > 48 * 1024) {
+    const int64_t slots = (int64_t)a.K * a.cmax;
+    d.lds_keys = slots <= BS_LDS_KEYS_MAX ? (int)slots : 0;
+    d.tails_in_lds = (a.K <= BS_TAIL_K && a.cur_len + 1 - a.copy_from <= BS_TAIL_W &&
+                      a.cur_len - a.prompt_len + 1 <= BS_TAIL_W) ? 1 : 0;
+    const size_t lds_bytes = (size_t)d.lds_keys * sizeof(unsigned long long);
+    if (lds_bytes > 32 * 1024) {
         GRX_CHECK_HIP(hipFuncSetAttribute((const void*)beam_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)lds_bytes));
     }

@@ -4,6 +4,7 @@
 // allowed tokens of the row (children of its trie node) are gathered while the
 // stream is in flight and finished once the row's log-sum-exp is known.
 #include <hip/hip_bf16.h>
+#include <hip/hip_ext.h>
 #include <hip/hip_fp16.h>
 #include <math.h>
 #include <string.h>
@@ -31,9 +32,9 @@ struct MlsArgs {
     TrieView tv;
     grx_state_words* st;   // may be null (fixed-hint without error reporting)
     int slot;              // state slot this call owns (count mode)
-    int mode;              // GRX_MODE_*
     int prefix_index;
-    PrefixArg pfx;
+    int pfx_n;             // length of prefix_ids, -1 = None
+    PrefixArg pfx;         // read by the fixed-hint instantiation only
     const int64_t* ids;    // [R, T] token rows
     int64_t ids_stride;
     int T;
@@ -44,9 +45,8 @@ struct MlsArgs {
     int eos;
     void* out;             // full modes
     int64_t out_stride;
-    int32_t* cand_count;   // compact mode
-    int32_t* cand_tok;
-    float* cand_logp;
+    grx_cand* cand;        // compact mode: [R, cand_stride] rows of {token, logp} behind a {count, lse} header
+    int64_t cand_stride;
     int cmax;
 };
 
@@ -81,6 +81,19 @@ struct RowStream {
 #endif
     }
 };
+
+#ifndef MLS_NTST
+#define MLS_NTST 0        // 1: non-temporal stores for the candidate rows
+#endif
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void cand_store(grx_cand* p, const grx_cand& v) {
+    const i32x2 w = {v.x, v.y};
+#if MLS_NTST
+    __builtin_nontemporal_store(w, reinterpret_cast<i32x2*>(p));
+#else
+    *reinterpret_cast<i32x2*>(p) = w;
+#endif
+}
 
 // ---- element traits --------------------------------------------------------
 template <int DT> struct Elem;
@@ -184,7 +197,7 @@ __device__ __forceinline__ MaxSum block_combine(MaxSum a, float* s_m, float* s_s
 // DT: element type of the logits.  OUT: OUT_*.  VEC: rows (and, for the full
 // modes, output rows) are 16-byte aligned so the stream uses 16-byte accesses;
 // otherwise one element per access.
-template <int DT, int OUT, bool VEC>
+template <int DT, int OUT, bool VEC, int MODE>
 __global__ __launch_bounds__(MLS_THREADS) void masked_lsm_kernel(MlsArgs a) {
     typedef Elem<DT> E;
     typedef typename E::T T;
@@ -195,19 +208,30 @@ __global__ __launch_bounds__(MLS_THREADS) void masked_lsm_kernel(MlsArgs a) {
     const int tid = threadIdx.x;
     const T* __restrict__ row = reinterpret_cast<const T*>(a.scores) + (int64_t)r * a.scores_stride;
 
+    // The first batch of the stream is issued before anything else: the row
+    // resolution below runs on scalar loads, which do not queue behind it.
+    const int nvec = a.V / EPV;
+    const RowStream vp(row, (int64_t)nvec * 16);
+    u32x4 v_head[MLS_UNROLL];
+    const bool head = VEC && (tid + (MLS_UNROLL - 1) * MLS_THREADS < nvec);
+    if (head) {
+#pragma unroll
+        for (int u = 0; u < MLS_UNROLL; ++u) v_head[u] = vp.load(tid + u * MLS_THREADS);
+    }
+
     // Which trie node governs this row.  Every wave resolves it redundantly from
     // wave-uniform addresses (a handful of cached loads), so the stream below can
     // start without a workgroup barrier.
     const int64_t* __restrict__ ids_row = a.ids + (int64_t)r * a.ids_stride;
     int code;
-    if (a.mode == GRX_MODE_COUNT) {
+    if (MODE == GRX_MODE_COUNT) {
         const int prev = (a.slot + 2) % 3;
         int count = state_count_after(*a.st, prev);
         if (r == 0 && tid == 0) {  // bookkeeping for the next call; no kernel of this call reads these words
             a.st->count[a.slot] = count;
             a.st->first_match[(a.slot + 1) % 3] = GRX_NO_MATCH;
         }
-        if (a.pfx.n >= 0 && r >= a.st->first_match[a.slot]) count = 0;  // the shared counter was reset at or before this row
+        if (a.pfx_n >= 0 && r >= a.st->first_match[a.slot]) count = 0;  // the shared counter was reset at or before this row
         const int start = py_tail_start(a.prefix_index + count, a.T);
         code = trie_walk(a.tv, ids_row + start, a.T - start);
     } else {
@@ -227,15 +251,19 @@ __global__ __launch_bounds__(MLS_THREADS) void masked_lsm_kernel(MlsArgs a) {
         c_n = 0;
     }
 
-    // Gather the first allowed logits now so they overlap the stream.
+    // Gather the first allowed logits now so they overlap the stream.  Slot k of a
+    // thread belongs to compact entry e = tid + k * threads, i.e. candidate e - 1
+    // (entry 0 is the row header), so that each store instruction of the epilogue
+    // covers whole 128-byte lines.
+    constexpr int SHIFT = (OUT == OUT_COMPACT) ? 1 : 0;
     int e_tok[MLS_EARLY];
     float e_val[MLS_EARLY];
 #pragma unroll
     for (int k = 0; k < MLS_EARLY; ++k) {
-        const int i = tid + k * MLS_THREADS;
+        const int i = tid + k * MLS_THREADS - SHIFT;
         e_tok[k] = -1;
         e_val[k] = 0.f;
-        if (i < c_n) {
+        if (i >= 0 && i < c_n) {
             e_tok[k] = (code == GRX_RES_EOS) ? a.eos : a.tv.tok[c_off + i];
             e_val[k] = E::to_float(row[e_tok[k]]);
         }
@@ -245,10 +273,8 @@ __global__ __launch_bounds__(MLS_THREADS) void masked_lsm_kernel(MlsArgs a) {
     MaxSum acc;
     acc.m = -INFINITY;
     acc.s = 0.f;
-    const int nvec = a.V / EPV;
 
     if (VEC) {
-        const RowStream vp(row, (int64_t)nvec * 16);
         u32x4* __restrict__ op = nullptr;
         if (OUT != OUT_COMPACT) {
             const size_t osz = (OUT == OUT_FULL_F32) ? sizeof(float) : sizeof(T);
@@ -259,11 +285,7 @@ __global__ __launch_bounds__(MLS_THREADS) void masked_lsm_kernel(MlsArgs a) {
         // 16-byte output vectors written per input vector
         constexpr int OPV = (OUT == OUT_FULL_F32) ? (E::kPerVec * 4) / 16 : 1;
 
-        int i = tid;
-        for (; i + (MLS_UNROLL - 1) * MLS_THREADS < nvec; i += MLS_UNROLL * MLS_THREADS) {
-            u32x4 v[MLS_UNROLL];
-#pragma unroll
-            for (int u = 0; u < MLS_UNROLL; ++u) v[u] = vp.load(i + u * MLS_THREADS);
+        auto consume = [&](const u32x4* v, int i) {
             if (OUT != OUT_COMPACT) {
 #pragma unroll
                 for (int u = 0; u < MLS_UNROLL; ++u)
@@ -274,6 +296,18 @@ __global__ __launch_bounds__(MLS_THREADS) void masked_lsm_kernel(MlsArgs a) {
 #pragma unroll
             for (int u = 0; u < MLS_UNROLL; ++u) E::unpack(v[u], f + u * E::kPerVec);
             accumulate<MLS_UNROLL * E::kPerVec>(acc, f);
+        };
+
+        int i = tid;
+        if (head) {
+            consume(v_head, i);
+            i += MLS_UNROLL * MLS_THREADS;
+        }
+        for (; i + (MLS_UNROLL - 1) * MLS_THREADS < nvec; i += MLS_UNROLL * MLS_THREADS) {
+            u32x4 v[MLS_UNROLL];
+#pragma unroll
+            for (int u = 0; u < MLS_UNROLL; ++u) v[u] = vp.load(i + u * MLS_THREADS);
+            consume(v, i);
         }
         for (; i < nvec; i += MLS_THREADS) {
             const u32x4 v = vp.load(i);
@@ -309,34 +343,56 @@ __global__ __launch_bounds__(MLS_THREADS) void masked_lsm_kernel(MlsArgs a) {
     const float log_s = logf(tot.s);
 
     // Emit the allowed tokens.
+    if (OUT == OUT_COMPACT) {
+        // Whole 128-byte lines only: header + candidates + zero padding up to the next 16 entries.
+        grx_cand* __restrict__ crow = a.cand + (int64_t)r * a.cand_stride;
+        const int n_line = ((c_n + 1 + 15) / 16) * 16;
 #pragma unroll
-    for (int k = 0; k < MLS_EARLY; ++k) {
-        const int i = tid + k * MLS_THREADS;
-        if (i < c_n) {
-            const float lp = (e_val[k] - tot.m) - log_s;
-            if (OUT == OUT_COMPACT) {
-                a.cand_tok[(int64_t)r * a.cmax + i] = e_tok[k];
-                a.cand_logp[(int64_t)r * a.cmax + i] = lp;
-            } else if (OUT == OUT_FULL_F32) {
-                reinterpret_cast<float*>(a.out)[(int64_t)r * a.out_stride + e_tok[k]] = lp;
+        for (int k = 0; k < MLS_EARLY; ++k) {
+            const int e = tid + k * MLS_THREADS;
+            if (e < n_line) {
+                grx_cand v = {0, 0};
+                if (e == 0) {
+                    v.x = c_n;
+                    v.y = __float_as_int(tot.m + log_s);
+                } else if (e - 1 < c_n) {
+                    v.x = e_tok[k];
+                    v.y = __float_as_int((e_val[k] - tot.m) - log_s);
+                }
+                cand_store(crow + e, v);
+            }
+        }
+        for (int e = tid + MLS_EARLY * MLS_THREADS; e < n_line; e += MLS_THREADS) {
+            grx_cand v = {0, 0};
+            if (e - 1 < c_n) {
+                v.x = a.tv.tok[c_off + e - 1];  // an EOS-only row has c_n == 1 and never gets here
+                v.y = __float_as_int((E::to_float(row[v.x]) - tot.m) - log_s);
+            }
+            cand_store(crow + e, v);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < MLS_EARLY; ++k) {
+            const int i = tid + k * MLS_THREADS;
+            if (i < c_n) {
+                const float lp = (e_val[k] - tot.m) - log_s;
+                if (OUT == OUT_FULL_F32) {
+                    reinterpret_cast<float*>(a.out)[(int64_t)r * a.out_stride + e_tok[k]] = lp;
+                } else {
+                    reinterpret_cast<T*>(a.out)[(int64_t)r * a.out_stride + e_tok[k]] = E::from_float(lp);
+                }
+            }
+        }
+        for (int i = tid + MLS_EARLY * MLS_THREADS; i < c_n; i += MLS_THREADS) {
+            const int tok = a.tv.tok[c_off + i];  // an EOS-only row has c_n == 1 and never gets here
+            const float lp = (E::to_float(row[tok]) - tot.m) - log_s;
+            if (OUT == OUT_FULL_F32) {
+                reinterpret_cast<float*>(a.out)[(int64_t)r * a.out_stride + tok] = lp;
             } else {
-                reinterpret_cast<T*>(a.out)[(int64_t)r * a.out_stride + e_tok[k]] = E::from_float(lp);
+                reinterpret_cast<T*>(a.out)[(int64_t)r * a.out_stride + tok] = E::from_float(lp);
             }
         }
     }
-    for (int i = tid + MLS_EARLY * MLS_THREADS; i < c_n; i += MLS_THREADS) {
-        const int tok = a.tv.tok[c_off + i];  // an EOS-only row has c_n == 1 and never gets here
-        const float lp = (E::to_float(row[tok]) - tot.m) - log_s;
-        if (OUT == OUT_COMPACT) {
-            a.cand_tok[(int64_t)r * a.cmax + i] = tok;
-            a.cand_logp[(int64_t)r * a.cmax + i] = lp;
-        } else if (OUT == OUT_FULL_F32) {
-            reinterpret_cast<float*>(a.out)[(int64_t)r * a.out_stride + tok] = lp;
-        } else {
-            reinterpret_cast<T*>(a.out)[(int64_t)r * a.out_stride + tok] = E::from_float(lp);
-        }
-    }
-    if (OUT == OUT_COMPACT && tid == 0) a.cand_count[r] = c_n;
 }
 
 // ---- optional kernel timing ---------------------------------------------------
@@ -377,19 +433,34 @@ static int timing_slot() {
 }
 
 // ---- launch -------------------------------------------------------------------
-template <int DT, int OUT>
-static void launch_vec(bool vec, const MlsArgs& a, hipStream_t stream) {
-    if (vec)
-        hipLaunchKernelGGL((masked_lsm_kernel<DT, OUT, true>), dim3(a.R), dim3(MLS_THREADS), 0, stream, a);
+// With events the dispatch itself carries them (start/stop timestamps of this
+// kernel only, no extra packets on the stream).
+template <typename KernelT>
+static void launch_one(KernelT kernel, const MlsArgs& a, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
+    if (ev0)
+        hipExtLaunchKernelGGL(kernel, dim3(a.R), dim3(MLS_THREADS), 0, stream, ev0, ev1, 0, a);
     else
-        hipLaunchKernelGGL((masked_lsm_kernel<DT, OUT, false>), dim3(a.R), dim3(MLS_THREADS), 0, stream, a);
+        hipLaunchKernelGGL(kernel, dim3(a.R), dim3(MLS_THREADS), 0, stream, a);
+}
+
+template <int DT, int OUT, bool VEC>
+static void launch_mode(int mode, const MlsArgs& a, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
+    if (mode == GRX_MODE_COUNT) launch_one(masked_lsm_kernel<DT, OUT, VEC, GRX_MODE_COUNT>, a, stream, ev0, ev1);
+    else launch_one(masked_lsm_kernel<DT, OUT, VEC, GRX_MODE_FIXED_HINT>, a, stream, ev0, ev1);
+}
+
+template <int DT, int OUT>
+static void launch_vec(bool vec, int mode, const MlsArgs& a, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
+    if (vec) launch_mode<DT, OUT, true>(mode, a, stream, ev0, ev1);
+    else launch_mode<DT, OUT, false>(mode, a, stream, ev0, ev1);
 }
 
 template <int OUT>
-static void launch_dtype(int dtype, bool vec, const MlsArgs& a, hipStream_t stream) {
-    if (dtype == GRX_F32) launch_vec<GRX_F32, OUT>(vec, a, stream);
-    else if (dtype == GRX_BF16) launch_vec<GRX_BF16, OUT>(vec, a, stream);
-    else launch_vec<GRX_F16, OUT>(vec, a, stream);
+static void launch_dtype(int dtype, bool vec, int mode, const MlsArgs& a, hipStream_t stream, hipEvent_t ev0,
+                         hipEvent_t ev1) {
+    if (dtype == GRX_F32) launch_vec<GRX_F32, OUT>(vec, mode, a, stream, ev0, ev1);
+    else if (dtype == GRX_BF16) launch_vec<GRX_BF16, OUT>(vec, mode, a, stream, ev0, ev1);
+    else launch_vec<GRX_F16, OUT>(vec, mode, a, stream, ev0, ev1);
 }
 
 static size_t dtype_size(int dt) { return dt == GRX_F32 ? 4 : 2; }
@@ -414,9 +485,9 @@ static int run_step(const char* who, const grx_trie* trie, grx_state* state, con
 
     a.tv = TrieView{trie->child_off, trie->child_tok};
     a.st = state ? state->dev : nullptr;
-    a.mode = con->mode;
     a.prefix_index = con->prefix_index;
     a.pfx = grx_prefix_arg(con);
+    a.pfx_n = a.pfx.n;
     a.ids = rows->input_ids;
     a.ids_stride = rows->ids_stride;
     a.T = rows->T;
@@ -427,15 +498,12 @@ static int run_step(const char* who, const grx_trie* trie, grx_state* state, con
     a.eos = con->eos_token_id;
     const bool vec = rows_16b_aligned(rows->scores, rows->scores_stride, dtype_size(rows->dtype)) && out_aligned;
     const int slot = timing_slot();
-    if (slot >= 0) GRX_CHECK_HIP(hipEventRecord(g_ev_start[slot], stream));
-    if (out_kind == OUT_COMPACT) launch_dtype<OUT_COMPACT>(rows->dtype, vec, a, stream);
-    else if (out_kind == OUT_FULL_F32) launch_dtype<OUT_FULL_F32>(rows->dtype, vec, a, stream);
-    else launch_dtype<OUT_FULL_SAME>(rows->dtype, vec, a, stream);
+    hipEvent_t ev0 = slot >= 0 ? g_ev_start[slot] : nullptr, ev1 = slot >= 0 ? g_ev_stop[slot] : nullptr;
+    if (out_kind == OUT_COMPACT) launch_dtype<OUT_COMPACT>(rows->dtype, vec, con->mode, a, stream, ev0, ev1);
+    else if (out_kind == OUT_FULL_F32) launch_dtype<OUT_FULL_F32>(rows->dtype, vec, con->mode, a, stream, ev0, ev1);
+    else launch_dtype<OUT_FULL_SAME>(rows->dtype, vec, con->mode, a, stream, ev0, ev1);
     GRX_CHECK_HIP(hipGetLastError());
-    if (slot >= 0) {
-        GRX_CHECK_HIP(hipEventRecord(g_ev_stop[slot], stream));
-        g_timing_n = slot + 1;
-    }
+    if (slot >= 0) g_timing_n = slot + 1;
     return GRX_OK;
 }
 
@@ -458,19 +526,25 @@ extern "C" int grx_constrained_logsoftmax(const grx_trie* trie, grx_state* state
                     (hipStream_t)stream);
 }
 
+extern "C" int64_t grx_candidate_stride(int32_t cmax) {
+    if (cmax < 0) return 0;
+    return (((int64_t)cmax + 1 + 15) / 16) * 16;
+}
+
 extern "C" int grx_constrained_candidates(const grx_trie* trie, grx_state* state, const grx_rows* rows,
-                                          const grx_constraint* con, int32_t* cand_count, int32_t* cand_tok,
-                                          float* cand_logp, int32_t cmax, void* workspace, size_t workspace_bytes,
-                                          void* stream) {
+                                          const grx_constraint* con, grx_cand* cand, int64_t cand_stride,
+                                          int32_t cmax, void* workspace, size_t workspace_bytes, void* stream) {
     const char* who = "grx_constrained_candidates";
     GRX_REQUIRE(rows != nullptr, GRX_E_INVALID, "%s: null rows", who);
     GRX_REQUIRE(cmax >= 1, GRX_E_INVALID, "%s: cmax must be >= 1", who);
-    GRX_REQUIRE(rows->R == 0 || (cand_count && cand_tok && cand_logp), GRX_E_INVALID, "%s: null output", who);
+    GRX_REQUIRE(cand_stride >= grx_candidate_stride(cmax) && cand_stride % 16 == 0, GRX_E_INVALID,
+                "%s: cand_stride must be a multiple of 16 and >= %lld", who, (long long)grx_candidate_stride(cmax));
+    GRX_REQUIRE(rows->R == 0 || (cand != nullptr && ((uintptr_t)cand & 127u) == 0), GRX_E_INVALID,
+                "%s: cand must be a 128-byte aligned device buffer", who);
     MlsArgs a;
     memset(&a, 0, sizeof(a));
-    a.cand_count = cand_count;
-    a.cand_tok = cand_tok;
-    a.cand_logp = cand_logp;
+    a.cand = cand;
+    a.cand_stride = cand_stride;
     a.cmax = cmax;
     return run_step(who, trie, state, rows, con, a, OUT_COMPACT, true, workspace, workspace_bytes,
                     (hipStream_t)stream);

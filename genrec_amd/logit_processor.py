@@ -50,6 +50,47 @@ class _DeviceState:
         self.ptr = None
 
 
+class Candidates:
+    """Compact candidate rows on the device (the ``grx_cand`` layout of the C ABI).
+
+    ``buf`` is int32 [rows, stride, 2]: entry 0 of a row is (count, bits of the
+    row's log-sum-exp), entry 1 + i is (token_i, bits of logp_i).  ``stride`` is a
+    multiple of 16 entries so every row starts on its own 128-byte line.
+    """
+
+    def __init__(self, rows: int, cmax: int, device):
+        self.rows, self.cmax = int(rows), int(cmax)
+        self.stride = int(_lib.lib().grx_candidate_stride(self.cmax))
+        self.buf = torch.empty((self.rows, self.stride, 2), dtype=torch.int32, device=device)
+        assert self.buf.data_ptr() % 128 == 0
+
+    @property
+    def count(self) -> torch.Tensor:
+        return self.buf[:, 0, 0]
+
+    @property
+    def logsumexp(self) -> torch.Tensor:
+        return self.buf[:, 0, 1].view(torch.float32)
+
+    @property
+    def tokens(self) -> torch.Tensor:
+        return self.buf[:, 1 : 1 + self.cmax, 0]
+
+    @property
+    def logp(self) -> torch.Tensor:
+        return self.buf[:, 1 : 1 + self.cmax, 1].view(torch.float32)
+
+    @classmethod
+    def from_parts(cls, count: torch.Tensor, tokens: torch.Tensor, logp: torch.Tensor, device) -> "Candidates":
+        """Pack separate (count [R], tokens [R, cmax], logp [R, cmax]) tensors."""
+        out = cls(count.shape[0], tokens.shape[1], device)
+        out.buf.zero_()
+        out.buf[:, 0, 0] = count.to(device=device, dtype=torch.int32)
+        out.buf[:, 1 : 1 + out.cmax, 0] = tokens.to(device=device, dtype=torch.int32)
+        out.buf[:, 1 : 1 + out.cmax, 1] = logp.to(device=device, dtype=torch.float32).view(torch.int32)
+        return out
+
+
 class _TrieConstrainedBase(LogitsProcessor):
     """State and launch plumbing shared by the count-based and fixed-hint processors."""
 
@@ -180,33 +221,23 @@ class _TrieConstrainedBase(LogitsProcessor):
             self.check_errors()
         return out
 
-    def candidates(self, input_ids: torch.LongTensor, scores: torch.Tensor, cmax: Optional[int] = None):
-        """Fused form of ``__call__``: ``(count[R], token[R, cmax], logp[R, cmax])``.
-
-        ``token[r, :count[r]]`` are the allowed next tokens of row ``r``
-        (ascending) and ``logp`` their full-vocabulary log-probabilities in
-        fp32 -- the finite entries of what ``__call__`` would return.  Advances
-        ``count`` exactly like ``__call__``.
-        """
-        rows, ids_keep, scores_keep = self._rows(input_ids, scores)
-        index = self._device_index(scores_keep)
-        dev = scores_keep.device
+    def candidates(self, input_ids: torch.LongTensor, scores: torch.Tensor, cmax: Optional[int] = None
+                   ) -> "Candidates":
+        """Fused form of ``__call__``: the allowed next tokens of every row and their
+        full-vocabulary log-probabilities (fp32) -- the finite entries of what
+        ``__call__`` would return -- as a :class:`Candidates` buffer.  Advances
+        ``count`` exactly like ``__call__``."""
         if cmax is None:
             cmax = max(self.trie.max_fanout, 1)
-        count = torch.empty(rows.R, dtype=torch.int32, device=dev)
-        tok = torch.empty((rows.R, cmax), dtype=torch.int32, device=dev)
-        logp = torch.empty((rows.R, cmax), dtype=torch.float32, device=dev)
-        self.candidates_into(input_ids, scores, count, tok, logp)
-        return count, tok, logp
+        cand = Candidates(input_ids.shape[0], cmax, scores.device)
+        self.candidates_into(input_ids, scores, cand)
+        return cand
 
-    def candidates_into(self, input_ids, scores, count: torch.Tensor, tok: torch.Tensor, logp: torch.Tensor) -> None:
-        """``candidates`` writing into caller-owned int32/int32/fp32 buffers (no allocation per step)."""
+    def candidates_into(self, input_ids, scores, cand: "Candidates") -> None:
+        """``candidates`` writing into a caller-owned buffer (no allocation per step)."""
         rows, ids_keep, scores_keep = self._rows(input_ids, scores)
         index = self._device_index(scores_keep)
-        cmax = tok.shape[1]
-        assert tok.is_contiguous() and logp.is_contiguous() and count.is_contiguous()
-        assert tok.dtype == torch.int32 and count.dtype == torch.int32 and logp.dtype == torch.float32
-        assert tok.shape == logp.shape and tok.shape[0] == rows.R and count.shape[0] == rows.R
+        assert cand.rows == rows.R and cand.buf.device == scores_keep.device
         with torch.cuda.device(index):
             st = self._state(index)
             ws = self._workspace(index, rows.R)
@@ -217,10 +248,9 @@ class _TrieConstrainedBase(LogitsProcessor):
                     st.ptr,
                     C.byref(rows),
                     C.byref(con),
-                    count.data_ptr(),
-                    tok.data_ptr(),
-                    logp.data_ptr(),
-                    cmax,
+                    cand.buf.data_ptr(),
+                    cand.stride,
+                    cand.cmax,
                     ws.data_ptr(),
                     ws.numel(),
                     _lib.current_stream_ptr(scores_keep.device),

@@ -141,16 +141,36 @@ GRX_API int grx_constrained_logsoftmax(const grx_trie* trie, grx_state* state, c
                                void* workspace, size_t workspace_bytes, void* stream);
 
 /*
+ * Compact candidate rows, the hand-off between the fused log-softmax and the
+ * beam step.  One row per logit row, made of 8-byte entries {int32 x, int32 y}:
+ *   entry 0      = {count, bits of the row's log-sum-exp (fp32)}
+ *   entry 1 + i  = {token_i, bits of logp_i (fp32)},  i < count, tokens ascending.
+ * The row stride (in entries) is a multiple of 16 and at least cmax + 1, and the
+ * buffer is 128-byte aligned, so every row starts on its own 128-byte line and is
+ * written in whole lines (entries between count + 1 and the next multiple of 16
+ * are zero-filled; anything beyond is left untouched).  Whole-line writes matter:
+ * masked partial-line writes into HBM cost a read-modify-write each and measurably
+ * slow the logit stream they are interleaved with.
+ */
+typedef struct grx_cand {
+    int32_t x;
+    int32_t y;
+} grx_cand;
+
+/* smallest valid row stride (entries) for rows of up to cmax candidates */
+GRX_API int64_t grx_candidate_stride(int32_t cmax);
+
+/*
  * Fused form of the same step: instead of the dense [R, V] result it emits,
- * per row, the allowed tokens and their log-probabilities --
- * cand_count[r] <= cmax, cand_tok[r, i] ascending, cand_logp[r, i] (fp32) --
- * which is everything the beam step below consumes.  Reads every logit once
- * and writes O(R * cmax).
+ * per row, the allowed tokens and their log-probabilities in the compact
+ * candidate format above -- the finite entries of what
+ * grx_constrained_logsoftmax would produce -- which is everything the beam
+ * step below consumes.  Reads every logit once and writes O(R * cmax).
+ * cand is device [R, cand_stride].
  */
 GRX_API int grx_constrained_candidates(const grx_trie* trie, grx_state* state, const grx_rows* rows,
-                               const grx_constraint* con, int32_t* cand_count, int32_t* cand_tok,
-                               float* cand_logp, int32_t cmax, void* workspace, size_t workspace_bytes,
-                               void* stream);
+                                       const grx_constraint* con, grx_cand* cand, int64_t cand_stride, int32_t cmax,
+                                       void* workspace, size_t workspace_bytes, void* stream);
 
 /*
  * Kernel timing for benchmarks (no counterpart in the reference).  While
@@ -189,9 +209,8 @@ typedef struct grx_beam_step_args {
     int32_t eos_token_id;   /* -1: none                                             */
     int32_t early_stopping; /* 0 False, 1 True, 2 "never"                           */
     float length_penalty;
-    const int32_t* cand_count; /* [B*K]                                             */
-    const int32_t* cand_tok;   /* [B*K, cmax]                                       */
-    const float* cand_logp;    /* [B*K, cmax]                                       */
+    const grx_cand* cand;      /* [B*K, cand_stride] compact candidate rows         */
+    int64_t cand_stride;       /* entries per row                                   */
     /* running beams */
     const int64_t* run_seq_in;  int64_t* run_seq_out;      /* [B, K, max_length]     */
     const float* run_score_in;  float* run_score_out;      /* [B, K]                 */

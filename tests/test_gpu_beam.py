@@ -8,6 +8,8 @@ import torch
 
 from helpers import load_npz
 
+from genrec_amd.logit_processor import Candidates
+
 pytestmark = pytest.mark.gpu
 
 LIVE = -1.0e8      # slots below are -1e9 placeholders / -inf fillers (order unspecified in torch.topk)
@@ -90,7 +92,7 @@ def test_beam_step_matches_oracle_stepwise(case):
             cmax = int((dense > float("-inf")).sum(dim=1).max())
             cnt, tok, lp = compact_from_dense(dense, cmax)
             tr = ref.step(dense)
-            res = st.step(cnt.to(dev), tok.to(dev), lp.to(dev), V)
+            res = st.step(Candidates.from_parts(cnt, tok, lp, dev), V)
             live = tr.topk_scores > LIVE
             assert torch.equal(res.topk_scores.cpu()[live], tr.topk_scores[live])   # same fp32 adds -> bit-exact
             assert torch.equal(res.topk_token.cpu().long()[live], tr.topk_token[live])
@@ -141,7 +143,7 @@ def test_beam_step_large_random_against_oracle():
                 lp[r, :n] = vals
                 dense[r, cols] = vals
             tr = ref.step(dense)
-            res = st.step(cnt.to(dev), tok.to(dev), lp.to(dev), V)
+            res = st.step(Candidates.from_parts(cnt, tok, lp, dev), V)
             live = tr.topk_scores > LIVE
             assert torch.equal(res.topk_scores.cpu()[live], tr.topk_scores[live])
             assert torch.equal(res.topk_token.cpu().long()[live], tr.topk_token[live])
@@ -165,6 +167,6 @@ def test_tie_order_is_canonical():
     cnt = torch.full((K,), 3, dtype=torch.int32, device=dev)
     tok = torch.tensor([[10, 20, 30]] * K, dtype=torch.int32, device=dev)
     lp = torch.full((K, 3), -1.0, device=dev)
-    res = st.step(cnt, tok, lp, V)
+    res = st.step(Candidates.from_parts(cnt, tok, lp, dev), V)
     assert res.topk_parent.cpu().tolist() == [[0, 0, 0, 1, 1, 1, 2, 2]]
     assert res.topk_token.cpu().tolist() == [[10, 20, 30, 10, 20, 30, 10, 20]]

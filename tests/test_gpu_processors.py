@@ -79,9 +79,11 @@ def test_candidates_match_dense_golden(case):
     for i in range(meta["cases"][case]["steps"]):
         ids = torch.from_numpy(data[f"{case}.ids.{i}"]).to(dev)
         scores = torch.from_numpy(data[f"{case}.scores.{i}"]).to(dev)
-        count, tok, logp = proc.candidates(ids, scores)
+        cand = proc.candidates(ids, scores)
         want = data[f"{case}.out.{i}"]
-        count, tok, logp = count.cpu().numpy(), tok.cpu().numpy(), logp.cpu().numpy()
+        count, tok, logp = cand.count.cpu().numpy(), cand.tokens.cpu().numpy(), cand.logp.cpu().numpy()
+        lse = torch.logsumexp(scores.double(), dim=-1).cpu().numpy()
+        assert np.max(np.abs(cand.logsumexp.cpu().numpy() - lse)) <= FP32_TOL
         for r in range(want.shape[0]):
             cols = np.nonzero(np.isfinite(want[r]))[0]
             assert count[r] == len(cols)
@@ -188,13 +190,15 @@ def test_full_vocab_rows_fp32_and_bf16(tmp_path):
         gen = torch.Generator().manual_seed(meta["seed"] + step)
         logits = torch.randn(ids.shape[0], V, generator=gen) * meta["scale"]
         n = data[f"count.{step}"]
-        count, tk, lp = p32.candidates(ids, logits.to(dev), cmax=trie.max_fanout)
+        c32 = p32.candidates(ids, logits.to(dev), cmax=trie.max_fanout)
+        count, tk, lp = c32.count, c32.tokens, c32.logp
         assert np.array_equal(count.cpu().numpy(), n)
         exact = torch.log_softmax(logits.double(), dim=-1).numpy()
         check(tk, lp, n, data[f"tok.{step}"], data[f"logp.{step}"], exact, FP32_TOL)
 
         l16 = logits.to(torch.bfloat16)
-        c16, t16, lp16 = p16.candidates(ids, l16.to(dev), cmax=trie.max_fanout)
+        cb16 = p16.candidates(ids, l16.to(dev), cmax=trie.max_fanout)
+        c16, t16, lp16 = cb16.count, cb16.tokens, cb16.logp
         assert np.array_equal(c16.cpu().numpy(), n)
         exact16 = torch.log_softmax(l16.double(), dim=-1).numpy()
         check(t16, lp16, n, data[f"tok.{step}"], data[f"logp_bf16.{step}"], exact16, BF16_TOL)
@@ -247,9 +251,9 @@ def test_ragged_vocab_widths_against_oracle(V, dtype):
     else:
         lim = tol if dtype == torch.float32 else 1e-2  # fp16 output rounding
         assert (got32 - want)[torch.isfinite(want)].abs().max() <= lim
-    c, t, lp = proc.candidates(ids.to(dev), scores.to(dev))  # count advanced to 2 -> rewind first
-    proc.count = 1
-    c, t, lp = proc.candidates(ids.to(dev), scores.to(dev))
+    proc.count = 1  # the dense call above advanced the counter
+    cb = proc.candidates(ids.to(dev), scores.to(dev))
+    c, t, lp = cb.count, cb.tokens, cb.logp
     for r in range(ids.shape[0]):
         cols = torch.nonzero(torch.isfinite(want[r])).flatten()
         assert c[r].item() == cols.numel()

@@ -9,15 +9,10 @@ build() { # name, extra flags
   /opt/rocm/bin/hipcc $FLAGS $2 $SRC -o build/variants/lib_$1.so &
 }
 build base ""
-build nt "-DMLS_NT=1"
-build nt_t512 "-DMLS_NT=1 -DMLS_THREADS=512"
-build nt_u2 "-DMLS_NT=1 -DMLS_UNROLL=2"
-build buf0 "-DMLS_BUF=1 -DMLS_AUX=0"
-build buf_nt "-DMLS_BUF=1 -DMLS_AUX=2"
-build buf_sc0 "-DMLS_BUF=1 -DMLS_AUX=1"
-build buf_sc1 "-DMLS_BUF=1 -DMLS_AUX=16"
-build buf_sc1nt "-DMLS_BUF=1 -DMLS_AUX=18"
-build buf_sc0nt "-DMLS_BUF=1 -DMLS_AUX=3"
-build buf_all "-DMLS_BUF=1 -DMLS_AUX=19"
+build ntst "-DMLS_NTST=1"
+build wg16 "-DMLS_WG_PER_CU=16"
+build wg32 "-DMLS_WG_PER_CU=32"
+build wg6 "-DMLS_WG_PER_CU=6"
+build ntst_wg16 "-DMLS_NTST=1 -DMLS_WG_PER_CU=16"
 wait
 ls -la build/variants
