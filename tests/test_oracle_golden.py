@@ -1,0 +1,202 @@
+"""CPU: the oracle (restatement of the reference) against the golden vectors captured
+from the real reference, and against the known answers in the reference's tests/docs."""
+
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import INDEX_NAMES, load_json_gz, load_npz, write_index_file
+from oracle import beam as obeam
+from oracle import processors as oproc
+from oracle import scoring as oscore
+
+
+def test_trie_queries_match_reference(tmp_path):
+    from genrec_amd.synth import ASSISTANT_PREFIX, SidTokenizer
+
+    gold = load_json_gz("tries.json.gz")
+    for name in INDEX_NAMES:
+        g = gold[name]
+        path = write_index_file(name, tmp_path)
+        tok = SidTokenizer.from_index(path)
+        trie, suffix, pidx = oproc.ref_build_trie_from_index(path, tok, prefix=ASSISTANT_PREFIX)
+        assert (len(trie), suffix, pidx) == (g["n_unique_items"], g["prefix_ids"], g["prefix_index"])
+        assert tok.vocab_size_padded == g["vocab_padded"] and len(tok.new_tokens) == g["n_sid_tokens"]
+        for q, a in zip(g["queries"], g["answers"]):
+            assert sorted(trie.get(q)) == a
+
+
+def _oracle_processor(case, fn, meta):
+    K, prefix, eos = meta["K"], meta["prefix"], meta["eos"]
+    if case in ("count_rl", "count_midloop_reset"):
+        return oproc.RefConstrainedLogitsProcessor(fn, K, 3, prefix, eos)
+    if case == "count_eval":
+        return oproc.RefConstrainedLogitsProcessor(fn, K, 3, None, eos)
+    if case == "count_seeded2":
+        return oproc.RefConstrainedLogitsProcessor(fn, K, 3, prefix, eos, initial_count=2)
+    return oproc.RefFixedHintConstrainedLogitsProcessor(fn, K, 3, prefix, eos)
+
+
+@pytest.mark.parametrize("case", ["count_rl", "count_eval", "count_seeded2", "count_midloop_reset", "fixed_hint"])
+def test_processor_oracle_bit_exact_with_reference(case):
+    data, meta = load_npz("processors.npz")
+    trie = oproc.DictTrie(data["trie_sequences"].tolist())
+    proc = _oracle_processor(case, trie.get, meta)
+    info = meta["cases"][case]
+    for i in range(info["steps"]):
+        out = proc(torch.from_numpy(data[f"{case}.ids.{i}"]), torch.from_numpy(data[f"{case}.scores.{i}"]))
+        assert np.array_equal(out.numpy(), data[f"{case}.out.{i}"])  # same torch ops in the same order
+        if info["counts_after"][i] >= 0:
+            assert proc.count == info["counts_after"][i]
+
+
+def test_processor_oracle_error_cases():
+    data, meta = load_npz("processors.npz")
+    trie = oproc.DictTrie(data["trie_sequences"].tolist())
+    K, prefix, eos, V = meta["K"], meta["prefix"], meta["eos"], meta["V"]
+    bad = torch.from_numpy(data["bad_rows"])
+    scores = torch.zeros(bad.shape[0], V)
+    want = {e["processor"]: e for e in meta["errors"]}
+    p = oproc.RefConstrainedLogitsProcessor(trie.get, K, 3, None, eos)
+    p.count = 1
+    with pytest.raises(AssertionError) as e:
+        p(bad, scores)
+    assert str(e.value)[:60] == want["count"]["message"]
+    f = oproc.RefFixedHintConstrainedLogitsProcessor(trie.get, K, 3, prefix, eos)
+    with pytest.raises(ValueError) as e:
+        f(bad, scores)
+    assert str(e.value)[:60] == want["fixed"]["message"]
+    with pytest.raises(ValueError) as e:
+        f(torch.from_numpy(data["noprefix_rows"]), scores)
+    assert str(e.value)[:60] == want["fixed_noprefix"]["message"]
+
+
+def test_reference_unit_test_known_answers():
+    """tests/test_fixed_hint_runtime.py:75-105,185-192 and
+    tests/test_fixed_hint_logit_processor_selection.py:36-65 of the reference."""
+    calls = []
+
+    def allowed(ids):
+        calls.append(list(ids))
+        return [0]
+
+    p = oproc.RefConstrainedLogitsProcessor(allowed, 2, 3, [101, 102, 103], 0)
+    p(torch.tensor([[9, 101, 102, 103], [9, 101, 102, 103]]), torch.zeros(2, 10))
+    assert calls == [[101, 102, 103], [101, 102, 103]]
+
+    def only_full(ids):
+        return [7] if ids == [101, 102, 103, 9001, 101, 102, 103] else []
+
+    assert oproc.fixed_hint_allowed_row([101, 102, 103, 9001, 101, 102, 103], [101, 102, 103], only_full, None) == [7]
+    assert oproc.fixed_hint_allowed_row([101, 102, 103, 999], [101, 102, 103], lambda ids: [], 999) == [999]
+
+    from genrec_amd.fixed_hint_logit_processor import (
+        find_last_prefix_match_start,
+        find_valid_prefix_match_start,
+        resolve_allowed_tokens_for_sequence,
+    )
+
+    sent = [1, 2, 3, 101, 102, 103, 9001, 9002, 42]
+    assert find_last_prefix_match_start(sent, [101, 102, 103]) == 3
+    assert find_valid_prefix_match_start([101, 102, 103, 9001, 101, 102, 103], [101, 102, 103], only_full) == 0
+    assert resolve_allowed_tokens_for_sequence([101, 102, 103, 999], [101, 102, 103], lambda ids: [], 999) == [999]
+    with pytest.raises(ValueError):
+        find_last_prefix_match_start([1, 2], [5])
+
+
+@pytest.mark.parametrize("case", ["count_k4_lp1", "count_k16_lp0", "count_k16_lp1", "fixed_k8_lp1"])
+def test_beam_oracle_reproduces_generate(case):
+    """Processor outputs recorded from transformers.generate -> oracle loop -> same sequences,
+    scores and beam indices (live beams)."""
+    data, meta = load_npz("beams.npz")
+    info = meta["cases"][case]
+    K = info["K"]
+    prompts = torch.from_numpy(data[f"{case}.prompts"])
+    st = obeam.RefBeamSearch(prompts.repeat_interleave(K, dim=0), K, prompts.shape[1] + info["max_new_tokens"],
+                             meta["eos"], meta["pad"], info["length_penalty"], False)
+    for t in range(info["steps"]):
+        assert st.has_unfinished()
+        st.step(torch.from_numpy(data[f"{case}.scores.{t}"]))
+    assert not st.has_unfinished()
+    seqs, scores, bidx = st.finalize()
+    want_scores = torch.from_numpy(data[f"{case}.sequences_scores"])
+    live = want_scores > -1e8
+    assert torch.equal(scores[live], want_scores[live])
+    assert torch.equal(seqs[live], torch.from_numpy(data[f"{case}.sequences"])[live])
+    assert torch.equal(bidx[live], torch.from_numpy(data[f"{case}.beam_indices"])[live])
+
+
+@pytest.mark.parametrize("case", ["count_k16_lp1", "fixed_k8_lp1"])
+def test_whole_oracle_pipeline_from_raw_logits(case):
+    """Raw logits -> log_softmax -> oracle processor -> oracle beam loop == generate()."""
+    data, meta = load_npz("beams.npz")
+    info = meta["cases"][case]
+    K, prefix, eos = info["K"], meta["prefix"], meta["eos"]
+    trie = oproc.DictTrie(data["trie_sequences"].tolist())
+    cls = oproc.RefFixedHintConstrainedLogitsProcessor if case.startswith("fixed") else oproc.RefConstrainedLogitsProcessor
+    proc = cls(trie.get, K, 3, prefix, eos)
+    prompts = torch.from_numpy(data[f"{case}.prompts"])
+    logits = [torch.from_numpy(data[f"{case}.logits.{t}"]) for t in range(info["steps"])]
+    st, traces = obeam.ref_constrained_beam_search(lambda step, flat: logits[step], proc, prompts, K,
+                                                   info["max_new_tokens"], eos, meta["pad"], info["length_penalty"])
+    assert len(traces) == info["steps"]
+    seqs, scores, _ = st.finalize()
+    want_scores = torch.from_numpy(data[f"{case}.sequences_scores"])
+    live = want_scores > -1e8
+    assert torch.equal(scores[live], want_scores[live])
+    assert torch.equal(seqs[live], torch.from_numpy(data[f"{case}.sequences"])[live])
+
+
+def test_scoring_oracle_matches_reference_golden():
+    g = load_json_gz("scoring.json.gz")
+    K = g["K"]
+    assert g["token_prefix_statics_checked"] is True  # _group_normalize(_tokenwise) were compared with the reference
+    assert oscore.ref_rule_reward(g["comps"], g["gts"], g["hints"]) == g["rule"]
+    assert oscore.ref_prefix_reward(g["comps"], g["gts"], g["hints"], True) == g["prefix_norm"]
+    assert oscore.ref_prefix_reward(g["comps"], g["gts"], g["hints"], False) == g["prefix_raw"]
+    assert oscore.ref_ndcg_reward(g["comps"], g["gts"], K, g["hints"]) == g["ndcg"]
+    assert oscore.ref_rule_reward(g["comps2"], g["gts2"]) == g["rule2"]
+    assert oscore.ref_prefix_reward(g["comps2"], g["gts2"]) == g["prefix2"]
+    assert oscore.ref_ndcg_reward(g["comps2"], g["gts2"], K) == g["ndcg2"]
+    assert oscore.ref_compute_metrics(g["metrics_data"]) == g["metrics"]
+
+
+def test_docs_worked_examples():
+    """docs/2026-03-13-genrec-rl-reward-forms.md:119,216-221,283-301,358-380,407-423 of the reference."""
+    assert [round(w, 4) for w in oscore.ndcg_rank_weights(4)] == [-0.3904, -0.2463, -0.1952, -0.1681]
+    gts = ["<a_10><b_20><c_30><d_40>"] * 4
+    comps = ["<a_10><b_20><c_30><d_40>", "<a_10><b_20><c_30><d_99>", "<a_10><b_99><c_88><d_77>",
+             "<a_99><b_88><c_77><d_66>"]
+    assert oscore.ref_rule_reward(comps, gts) == [1.0, 0.0, 0.0, 0.0]
+    assert oscore.ref_prefix_reward(comps, gts) == [1.0, 0.75, 0.25, 0.0]
+    ndcg = oscore.ref_ndcg_reward(comps, gts, 4)
+    assert [round(x, 4) for x in ndcg] == [0.0, -0.2463, -0.1952, -0.1681]
+    prefix_tok = torch.tensor([[0.25] * 4, [0.25, 0.25, 0.25, 0], [0.25, 0, 0, 0], [0.0] * 4])
+    ones = torch.ones(4, 4)
+    got = oscore.ref_group_normalize_tokenwise(prefix_tok, ones, 4)
+    want = torch.tensor([[0.5749, 0.9968, 0.9968, 1.7247], [0.5749, 0.9968, 0.9968, -0.5749],
+                         [0.5749, -0.9968, -0.9968, -0.5749], [-1.7247, -0.9968, -0.9968, -0.5749]])
+    assert torch.allclose(got, want, atol=1e-4)
+    total = prefix_tok + torch.tensor(ndcg, dtype=torch.float32).unsqueeze(1)
+    got = oscore.ref_group_normalize_tokenwise(total, ones, 4)
+    want = torch.tensor([[1.4386, 1.5613, 1.5613, 1.7124], [-0.2102, 0.1751, 0.1751, -0.7879],
+                         [0.1320, -0.9443, -0.9443, -0.5304], [-1.3604, -0.7920, -0.7920, -0.3941]])
+    assert torch.allclose(got, want, atol=1e-4)
+    err = torch.tensor([[0, 0, 0, 0], [0, 0, 0, 1], [0, 1, 1, 1], [1, 1, 1, 1]], dtype=torch.float32)
+    errtok = prefix_tok + torch.tensor(ndcg, dtype=torch.float32).unsqueeze(1) * err
+    got = oscore.ref_group_normalize_tokenwise(errtok, ones, 4)
+    want = torch.tensor([[0.5765, 0.9980, 0.9980, 1.7124], [0.5765, 0.9980, 0.9980, -0.7879],
+                         [0.5765, -1.0605, -1.0605, -0.5304], [-1.7294, -0.9354, -0.9354, -0.3941]])
+    assert torch.allclose(got, want, atol=1e-4)
+    # prefix_token: sequence-normalised prefix advantage spread over matched tokens + broadcast ndcg advantage
+    adv_p = oscore.ref_group_normalize(torch.tensor([1.0, 0.75, 0.25, 0.0]), 4)
+    adv_n = oscore.ref_group_normalize(torch.tensor(ndcg, dtype=torch.float32), 4)
+    mass = prefix_tok.sum(dim=1, keepdim=True)
+    dist = torch.where(mass > 0, prefix_tok / (mass + 1e-8), torch.zeros_like(prefix_tok))
+    tok_adv = adv_p.unsqueeze(1) * dist + adv_n.unsqueeze(1) * ones
+    want = torch.tensor([[1.7015] * 4, [-0.6971, -0.6971, -0.6971, -0.8796], [-0.9484, -0.4008, -0.4008, -0.4008],
+                         [-0.1473] * 4])
+    assert torch.allclose(tok_adv, want, atol=1e-4)
+    assert math.isclose(float(oscore.ref_ndcg_rank_penalties(8, 4, 1)[5]), -0.2463, abs_tol=1e-4)
