@@ -172,6 +172,31 @@ def time_cpu_baseline(args, wl):
     }
 
 
+def recorded_traffic(args, alg_bytes):
+    """HBM bytes per launch of the dominant kernel from hardware counters.
+
+    Counters cannot be read from inside this process: they come from separate
+    `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` passes over this same
+    command, whose per-launch averages are kept in profiles/*_pmc_summary.json
+    (FETCH_SIZE is in KiB and, on gfx950, counts half the bytes of a wide
+    coalesced stream, hence the factor 2 applied there).  The recorded figure
+    only applies to the workload it was collected on; anything else reports null.
+    """
+    import glob
+
+    if args.processor != "count" or args.dtype != "bf16" or args.trie != "Instruments":
+        return None, None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
+    if not files:
+        return None, None
+    with open(files[-1]) as f:
+        rec = json.load(f)["masked_lsm_kernel_hbm_bytes_per_launch"]
+    if int(rec["algorithmic"]) != int(alg_bytes):
+        return None, None
+    return float(rec["total"]), os.path.relpath(files[-1], ROOT)
+
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -244,6 +269,7 @@ def main() -> None:
         kernel_ms = tot.value / n.value if n.value else float("nan")
         alg_bytes = R * wl["V"] * esize
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        traffic, traffic_source = recorded_traffic(args, alg_bytes)
         out = {
             "metric": "constrained decode steps/sec (batch x beam = 8192, V ~ 152k)",
             "value": world * args.steps / elapsed,
@@ -274,7 +300,8 @@ def main() -> None:
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_source": traffic_source,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "kernel_ms": kernel_ms,
                 "launches_timed": n.value,
