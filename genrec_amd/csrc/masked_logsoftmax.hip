@@ -9,6 +9,8 @@
 #include <math.h>
 #include <string.h>
 
+#include <type_traits>
+
 #include "common.h"
 #include "resolve.h"
 
@@ -85,6 +87,16 @@ struct RowStream {
 #ifndef MLS_NTST
 #define MLS_NTST 0        // 1: non-temporal stores for the candidate rows
 #endif
+#ifndef MLS_NTFILL
+#define MLS_NTFILL 0      // 1: non-temporal stores for the -inf fill of the dense output
+#endif
+__device__ __forceinline__ void fill_store(u32x4* p, const u32x4& v) {
+#if MLS_NTFILL
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
 typedef int i32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void cand_store(grx_cand* p, const grx_cand& v) {
     const i32x2 w = {v.x, v.y};
@@ -145,6 +157,13 @@ template <> struct Elem<GRX_F16> {
     }
     static constexpr uint32_t kNegInfPacked = 0xFC00FC00u;
 };
+
+// Output element of a dense mode: fp32, or the input element type.
+template <int DT, int OUT>
+__device__ __forceinline__ auto to_out(float v) {
+    if constexpr (OUT == OUT_FULL_F32) return v;
+    else return Elem<DT>::from_float(v);
+}
 
 // ---- online softmax accumulator ---------------------------------------------
 struct MaxSum {
@@ -275,23 +294,10 @@ __global__ __launch_bounds__(MLS_THREADS) void masked_lsm_kernel(MlsArgs a) {
     acc.s = 0.f;
 
     if (VEC) {
-        u32x4* __restrict__ op = nullptr;
-        if (OUT != OUT_COMPACT) {
-            const size_t osz = (OUT == OUT_FULL_F32) ? sizeof(float) : sizeof(T);
-            op = reinterpret_cast<u32x4*>(reinterpret_cast<char*>(a.out) + (int64_t)r * a.out_stride * osz);
-        }
-        const uint32_t ninf = (OUT == OUT_FULL_F32) ? 0xFF800000u : E::kNegInfPacked;
-        const u32x4 fill = {ninf, ninf, ninf, ninf};
-        // 16-byte output vectors written per input vector
-        constexpr int OPV = (OUT == OUT_FULL_F32) ? (E::kPerVec * 4) / 16 : 1;
-
+        // The dense output of a vectorised launch was filled with -inf by
+        // fill_rows_kernel beforehand (write-only and read-only traffic run
+        // faster back to back than interleaved), so the stream only reads.
         auto consume = [&](const u32x4* v, int i) {
-            if (OUT != OUT_COMPACT) {
-#pragma unroll
-                for (int u = 0; u < MLS_UNROLL; ++u)
-#pragma unroll
-                    for (int o = 0; o < OPV; ++o) op[(int64_t)(i + u * MLS_THREADS) * OPV + o] = fill;
-            }
             float f[MLS_UNROLL * E::kPerVec];
 #pragma unroll
             for (int u = 0; u < MLS_UNROLL; ++u) E::unpack(v[u], f + u * E::kPerVec);
@@ -311,10 +317,6 @@ __global__ __launch_bounds__(MLS_THREADS) void masked_lsm_kernel(MlsArgs a) {
         }
         for (; i < nvec; i += MLS_THREADS) {
             const u32x4 v = vp.load(i);
-            if (OUT != OUT_COMPACT) {
-#pragma unroll
-                for (int o = 0; o < OPV; ++o) op[(int64_t)i * OPV + o] = fill;
-            }
             float f[E::kPerVec];
             E::unpack(v, f);
             accumulate<E::kPerVec>(acc, f);
@@ -326,6 +328,7 @@ __global__ __launch_bounds__(MLS_THREADS) void masked_lsm_kernel(MlsArgs a) {
         for (int e = (VEC ? nvec * EPV : 0) + tid; e < a.V; e += MLS_THREADS) {
             float f[1] = {E::to_float(row[e])};
             accumulate<1>(acc, f);
+            if (VEC) continue;  // pre-filled
             if (OUT == OUT_FULL_F32) {
                 reinterpret_cast<float*>(a.out)[(int64_t)r * a.out_stride + e] = ninf_f;
             } else if (OUT == OUT_FULL_SAME) {
@@ -334,11 +337,12 @@ __global__ __launch_bounds__(MLS_THREADS) void masked_lsm_kernel(MlsArgs a) {
         }
     }
 
-    if (OUT != OUT_COMPACT) {
+    if (OUT != OUT_COMPACT && !VEC) {
         // The -inf fill of every thread must have reached memory before any
         // thread overwrites an allowed position.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    typedef typename std::conditional<OUT == OUT_FULL_F32, float, T>::type OT;
     const MaxSum tot = block_combine(acc, s_m, s_s);  // contains a workgroup barrier
     const float log_s = logf(tot.s);
 
@@ -371,28 +375,56 @@ __global__ __launch_bounds__(MLS_THREADS) void masked_lsm_kernel(MlsArgs a) {
             cand_store(crow + e, v);
         }
     } else {
+        OT* __restrict__ orow = reinterpret_cast<OT*>(a.out) + (int64_t)r * a.out_stride;
+        auto put = [&](int tok, float lp) {
+            orow[tok] = to_out<DT, OUT>(lp);
+        };
 #pragma unroll
         for (int k = 0; k < MLS_EARLY; ++k) {
             const int i = tid + k * MLS_THREADS;
-            if (i < c_n) {
-                const float lp = (e_val[k] - tot.m) - log_s;
-                if (OUT == OUT_FULL_F32) {
-                    reinterpret_cast<float*>(a.out)[(int64_t)r * a.out_stride + e_tok[k]] = lp;
-                } else {
-                    reinterpret_cast<T*>(a.out)[(int64_t)r * a.out_stride + e_tok[k]] = E::from_float(lp);
-                }
-            }
+            if (i < c_n) put(e_tok[k], (e_val[k] - tot.m) - log_s);
         }
         for (int i = tid + MLS_EARLY * MLS_THREADS; i < c_n; i += MLS_THREADS) {
             const int tok = a.tv.tok[c_off + i];  // an EOS-only row has c_n == 1 and never gets here
-            const float lp = (E::to_float(row[tok]) - tot.m) - log_s;
-            if (OUT == OUT_FULL_F32) {
-                reinterpret_cast<float*>(a.out)[(int64_t)r * a.out_stride + tok] = lp;
-            } else {
-                reinterpret_cast<T*>(a.out)[(int64_t)r * a.out_stride + tok] = E::from_float(lp);
-            }
+            put(tok, (E::to_float(row[tok]) - tot.m) - log_s);
         }
     }
+}
+
+// ---- dense output fill ---------------------------------------------------------
+// Writes -inf over V elements of every output row: 16-byte stores plus a scalar
+// tail.  One short-lived workgroup per FILL_CHUNK vectors of a row.
+#define FILL_THREADS 256
+#ifndef FILL_PER_THREAD
+#define FILL_PER_THREAD 1   // measured: one 16-byte store per thread over a huge grid writes fastest (6.9 TB/s)
+#endif
+#define FILL_CHUNK (FILL_THREADS * FILL_PER_THREAD)
+
+__global__ __launch_bounds__(FILL_THREADS) void fill_rows_kernel(void* out, int64_t row_bytes, int row_vecs,
+                                                                 int64_t V, int elsize, uint32_t packed_ninf,
+                                                                 int chunks) {
+    const int r = blockIdx.x / chunks;
+    const int chunk = blockIdx.x - r * chunks;
+    char* __restrict__ rowp = reinterpret_cast<char*>(out) + (int64_t)r * row_bytes;
+    u32x4* __restrict__ op = reinterpret_cast<u32x4*>(rowp);
+    const u32x4 fill = {packed_ninf, packed_ninf, packed_ninf, packed_ninf};
+    const int64_t base = (int64_t)chunk * FILL_CHUNK + threadIdx.x;
+#pragma unroll
+    for (int u = 0; u < FILL_PER_THREAD; ++u) {
+        const int64_t j = base + u * FILL_THREADS;
+        if (j < row_vecs) fill_store(op + j, fill);
+    }
+    if (chunk == chunks - 1) {  // elements behind the last whole vector
+        const int64_t done = (int64_t)row_vecs * (16 / elsize);
+        for (int64_t e = done + threadIdx.x; e < V; e += FILL_THREADS) {
+            if (elsize == 4) reinterpret_cast<uint32_t*>(rowp)[e] = packed_ninf;
+            else reinterpret_cast<uint16_t*>(rowp)[e] = (uint16_t)(packed_ninf & 0xFFFFu);
+        }
+    }
+}
+
+static uint32_t packed_neg_inf(int dtype) {
+    return dtype == GRX_F32 ? 0xFF800000u : (dtype == GRX_BF16 ? 0xFF80FF80u : 0xFC00FC00u);
 }
 
 // ---- optional kernel timing ---------------------------------------------------
@@ -437,7 +469,7 @@ static int timing_slot() {
 // kernel only, no extra packets on the stream).
 template <typename KernelT>
 static void launch_one(KernelT kernel, const MlsArgs& a, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
-    if (ev0)
+    if (ev0 || ev1)
         hipExtLaunchKernelGGL(kernel, dim3(a.R), dim3(MLS_THREADS), 0, stream, ev0, ev1, 0, a);
     else
         hipLaunchKernelGGL(kernel, dim3(a.R), dim3(MLS_THREADS), 0, stream, a);
@@ -499,6 +531,29 @@ static int run_step(const char* who, const grx_trie* trie, grx_state* state, con
     const bool vec = rows_16b_aligned(rows->scores, rows->scores_stride, dtype_size(rows->dtype)) && out_aligned;
     const int slot = timing_slot();
     hipEvent_t ev0 = slot >= 0 ? g_ev_start[slot] : nullptr, ev1 = slot >= 0 ? g_ev_stop[slot] : nullptr;
+    if (out_kind != OUT_COMPACT && vec) {
+        // Dense output, phase 1: -inf everywhere (write-only); the stream kernel then only reads
+        // and scatters the allowed positions.  A timed call spans both kernels.
+        const int odt = out_kind == OUT_FULL_F32 ? GRX_F32 : rows->dtype;
+        const int osz = (int)dtype_size(odt);
+        // contiguous rows are filled as one flat span (a single "row" of R * V elements)
+        const bool flat = a.out_stride == rows->V && (int64_t)rows->R * rows->V * osz / 16 <= 0x7FFFFFFF;
+        const int fill_rows = flat ? 1 : rows->R;
+        const int64_t fill_elems = flat ? (int64_t)rows->R * rows->V : rows->V;
+        const int row_vecs = (int)((fill_elems * osz) / 16);
+        const int chunks = row_vecs > 0 ? (row_vecs + FILL_CHUNK - 1) / FILL_CHUNK : 1;
+        GRX_REQUIRE((int64_t)chunks * fill_rows <= 0x7FFFFFFF, GRX_E_UNSUPPORTED, "%s: output too large", who);
+        const dim3 grid((unsigned)((int64_t)chunks * fill_rows));
+        if (ev0)
+            hipExtLaunchKernelGGL(fill_rows_kernel, grid, dim3(FILL_THREADS), 0, stream, ev0, nullptr, 0, a.out,
+                                  a.out_stride * osz, row_vecs, fill_elems, osz, packed_neg_inf(odt), chunks);
+        else
+            hipLaunchKernelGGL(fill_rows_kernel, grid, dim3(FILL_THREADS), 0, stream, a.out, a.out_stride * osz,
+                               row_vecs, fill_elems, osz, packed_neg_inf(odt), chunks);
+        GRX_CHECK_HIP(hipGetLastError());
+        ev0 = nullptr;
+
+    }
     if (out_kind == OUT_COMPACT) launch_dtype<OUT_COMPACT>(rows->dtype, vec, con->mode, a, stream, ev0, ev1);
     else if (out_kind == OUT_FULL_F32) launch_dtype<OUT_FULL_F32>(rows->dtype, vec, con->mode, a, stream, ev0, ev1);
     else launch_dtype<OUT_FULL_SAME>(rows->dtype, vec, con->mode, a, stream, ev0, ev1);

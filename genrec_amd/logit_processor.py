@@ -194,10 +194,24 @@ class _TrieConstrainedBase(LogitsProcessor):
         return t.device.index if t.device.index is not None else torch.cuda.current_device()
 
     # -- the processor surface -----------------------------------------------------------
-    def __call__(self, input_ids: torch.LongTensor, scores: torch.FloatTensor) -> torch.FloatTensor:
+    def __call__(self, input_ids: torch.LongTensor, scores: torch.FloatTensor,
+                 out: Optional[torch.Tensor] = None) -> torch.FloatTensor:
+        """``log_softmax(scores) + mask`` as a new [rows, vocab] tensor of the dtype of ``scores``
+        (logit_processor.py:29-49 / fixed_hint_logit_processor.py:79-96).
+
+        ``out`` is an extension: a caller-owned result tensor (fp32 or the dtype of
+        ``scores``; rows may be padded, i.e. ``out.stride(0) >= vocab``), which saves the
+        allocation and lets bf16 logits produce fp32 log-probs."""
         rows, ids_keep, scores_keep = self._rows(input_ids, scores)
         index = self._device_index(scores_keep)
-        out = torch.empty_like(scores_keep, memory_format=torch.contiguous_format)
+        if out is None:
+            out = torch.empty_like(scores_keep, memory_format=torch.contiguous_format)
+        else:
+            _lib.require_cuda(out, "out")
+            if out.shape != scores_keep.shape or out.device != scores_keep.device or out.stride(1) != 1:
+                raise ValueError("out must be a [rows, vocab] tensor on the device of scores with unit column stride")
+            if out.dtype not in (torch.float32, scores_keep.dtype):
+                raise ValueError("out must be float32 or have the dtype of scores")
         with torch.cuda.device(index):
             st = self._state(index)
             ws = self._workspace(index, rows.R)
@@ -210,7 +224,7 @@ class _TrieConstrainedBase(LogitsProcessor):
                     C.byref(con),
                     out.data_ptr(),
                     out.stride(0) if out.shape[0] > 1 else out.shape[1],
-                    rows.dtype,
+                    _lib.torch_dtype_code(out.dtype),
                     ws.data_ptr(),
                     ws.numel(),
                     _lib.current_stream_ptr(scores_keep.device),

@@ -261,6 +261,52 @@ def test_ragged_vocab_widths_against_oracle(V, dtype):
         assert (lp[r, : cols.numel()].cpu() - want[r, cols]).abs().max() <= FP32_TOL
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_caller_owned_output_padded_rows_and_fp32_results(dtype):
+    """`out=`: padded output rows (row-wise fill path) and fp32 log-probs from bf16 logits equal the
+    values of the plain call / the candidates."""
+    from genrec_amd.logit_processor import ConstrainedLogitsProcessor
+    from genrec_amd.trie import FlatTrie, create_prefix_allowed_tokens_fn
+
+    data, meta, _, _ = _small_setup()
+    dev = _dev()
+    trie = FlatTrie(data["trie_sequences"].tolist())
+    fn = create_prefix_allowed_tokens_fn(trie, meta["prefix"])
+    K, V = meta["K"], 4096
+    ids = torch.from_numpy(data["count_rl.ids.1"]).to(dev)
+    R = ids.shape[0]
+    torch.manual_seed(3)
+    scores = (torch.randn(R, V) * 5).to(dtype).to(dev)
+    proc = ConstrainedLogitsProcessor(fn, K, 3, meta["prefix"], meta["eos"], sync_errors=True)
+    proc.count = 1
+    plain = proc(ids, scores)
+    for pad in (0, 8, 5):  # 5 breaks the 16-byte row alignment: element-wise path
+        backing = torch.full((R, V + pad), 7.0, dtype=dtype, device=dev)
+        proc.count = 1
+        got = proc(ids, scores, out=backing[:, :V])
+        assert got.data_ptr() == backing.data_ptr()
+        if pad == 5:  # other summation order: same values up to rounding
+            assert torch.equal(torch.isfinite(got), torch.isfinite(plain))
+            fin = torch.isfinite(plain)
+            assert float((got.float()[fin] - plain.float()[fin]).abs().max()) <= (FP32_TOL if dtype == torch.float32 else 0.07)
+        else:
+            assert torch.equal(got, plain)
+        if pad:
+            assert bool((backing[:, V:] == 7.0).all()), "padding columns must stay untouched"
+    out32 = torch.empty((R, V), dtype=torch.float32, device=dev)
+    proc.count = 1
+    proc(ids, scores, out=out32)
+    proc.count = 1
+    cand = proc.candidates(ids, scores)
+    finite = torch.isfinite(out32)
+    assert torch.equal(finite.sum(dim=1).int(), cand.count)
+    valid = torch.arange(cand.cmax, device=dev)[None, :] < cand.count[:, None]
+    assert torch.equal(out32[finite], cand.logp[valid])  # same fp32 values, row-major token order
+    assert torch.equal(finite, torch.isfinite(plain))
+    with pytest.raises(ValueError):
+        proc(ids, scores, out=torch.empty((R, V), dtype=torch.float16, device=dev))
+
+
 def test_strided_inputs_and_unnormalised_extremes():
     """Non-contiguous views, very peaked rows and rows containing -inf."""
     from oracle.processors import DictTrie, RefFixedHintConstrainedLogitsProcessor

@@ -9,10 +9,8 @@ build() { # name, extra flags
   /opt/rocm/bin/hipcc $FLAGS $2 $SRC -o build/variants/lib_$1.so &
 }
 build base ""
-build ntst "-DMLS_NTST=1"
-build wg16 "-DMLS_WG_PER_CU=16"
-build wg32 "-DMLS_WG_PER_CU=32"
-build wg6 "-DMLS_WG_PER_CU=6"
-build ntst_wg16 "-DMLS_NTST=1 -DMLS_WG_PER_CU=16"
+build ntfill "-DMLS_NTFILL=1"
+build fpt4 "-DFILL_PER_THREAD=4"
+build fpt16nt "-DFILL_PER_THREAD=16 -DMLS_NTFILL=1"
 wait
 ls -la build/variants
