@@ -30,6 +30,24 @@ void grx_set_error(const char* fmt, ...);
     } while (0)
 
 // ------------------------------------------------------- opaque handles ---
+#define GRX_CHAIN_MAX 8
+
+// One slot of the open-addressing edge table; parent == -1 marks an empty slot.
+struct grx_edge_slot {
+    int32_t parent;
+    int32_t tok;
+    int32_t child;
+    int32_t pad;
+};
+
+__host__ __device__ __forceinline__ uint32_t grx_edge_hash(uint32_t parent, uint32_t tok) {
+    uint32_t h = parent * 0x9E3779B1u ^ (tok * 0x85EBCA6Bu);
+    h ^= h >> 15;
+    h *= 0x2C1B3C6Du;
+    h ^= h >> 13;
+    return h;
+}
+
 struct grx_trie {
     int32_t* child_off;  // device [n_nodes + 1]
     int32_t* child_tok;  // device [n_edges]
@@ -38,6 +56,13 @@ struct grx_trie {
     int32_t max_fanout;
     int32_t max_token;
     int device;
+    // Edge hash (parent, token) -> child for one-load lookups, and the unary chain
+    // below the root (the assistant-prefix tokens every item starts with).
+    struct grx_edge_slot* edge_hash;  // device [hash_mask + 1]
+    uint32_t hash_mask;
+    int32_t chain_n;
+    int32_t chain_tok[GRX_CHAIN_MAX];
+    int32_t chain_node;
 };
 
 // Device words behind grx_state.  The counter and the "a row ended in
@@ -69,28 +94,44 @@ struct grx_state {
 struct TrieView {
     const int32_t* __restrict__ off;
     const int32_t* __restrict__ tok;
+    const grx_edge_slot* __restrict__ hash;
+    uint32_t hash_mask;
+    int32_t chain_n;
+    int32_t chain_node;
+    int32_t chain_tok[GRX_CHAIN_MAX];
 };
 
-// Child of `node` along token `t`, or -1.  Binary search over the node's
-// ascending token list.
+// Child of `node` along token `t`, or -1.  One 16-byte load per probe of the
+// edge table (load factor <= 1/2), on wave-uniform addresses.
 __device__ __forceinline__ int trie_child(const TrieView& tv, int node, int64_t t) {
     if (t < 0 || t > 0x7FFFFFFFLL) return -1;
     const int32_t key = (int32_t)t;
-    int lo = tv.off[node];
-    const int end = tv.off[node + 1];
-    int hi = end;
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (tv.tok[mid] < key) lo = mid + 1; else hi = mid;
+    uint32_t h = grx_edge_hash((uint32_t)node, (uint32_t)key) & tv.hash_mask;
+    for (;;) {
+        const grx_edge_slot s = tv.hash[h];
+        if (s.parent == node && s.tok == key) return s.child;
+        if (s.parent < 0) return -1;
+        h = (h + 1) & tv.hash_mask;
     }
-    return (lo < end && tv.tok[lo] == key) ? lo + 1 : -1;
 }
 
 // Node reached from the root along ids[0..n), or GRX_RES_EMPTY when the path
 // leaves the trie or ends on a node without children (Trie.get returns []).
+// Rows normally start with the unary chain below the root, which is compared
+// against the kernel arguments instead of being walked.
 __device__ __forceinline__ int trie_walk(const TrieView& tv, const int64_t* __restrict__ ids, int n) {
-    int node = 0;
-    for (int i = 0; i < n; ++i) {
+    int node = 0, i = 0;
+    if (tv.chain_n > 0 && n >= tv.chain_n) {
+        bool same = true;
+#pragma unroll
+        for (int j = 0; j < GRX_CHAIN_MAX; ++j)
+            if (j < tv.chain_n) same = same && ids[j] == (int64_t)tv.chain_tok[j];
+        if (same) {
+            node = tv.chain_node;
+            i = tv.chain_n;
+        }
+    }
+    for (; i < n; ++i) {
         node = trie_child(tv, node, ids[i]);
         if (node < 0) return GRX_RES_EMPTY;
     }

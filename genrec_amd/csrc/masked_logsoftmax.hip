@@ -31,15 +31,12 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 enum { OUT_COMPACT = 0, OUT_FULL_F32 = 1, OUT_FULL_SAME = 2 };
 
 struct MlsArgs {
-    TrieView tv;
+    const int32_t* tok;    // child tokens of the trie (CSR)
+    const int32_t* off;    // child offsets of the trie (CSR)
+    const grx_row_plan* plan;  // [R] from the planning kernel of this call
     grx_state_words* st;   // may be null (fixed-hint without error reporting)
     int slot;              // state slot this call owns (count mode)
-    int prefix_index;
-    int pfx_n;             // length of prefix_ids, -1 = None
-    PrefixArg pfx;         // read by the fixed-hint instantiation only
-    const int64_t* ids;    // [R, T] token rows
-    int64_t ids_stride;
-    int T;
+    int reset_aware;       // count mode with prefix_ids: rows from first_match[slot] on use their count == 0 window
     int R;
     const void* scores;
     int64_t scores_stride;
@@ -50,6 +47,11 @@ struct MlsArgs {
     grx_cand* cand;        // compact mode: [R, cand_stride] rows of {token, logp} behind a {count, lse} header
     int64_t cand_stride;
     int cmax;
+    // Split rows (few rows): a row is streamed by S workgroups; the last one to
+    // finish merges the S partial (max, sum) pairs and emits the row.
+    int S;
+    int* split_count;      // [R] arrival counters, zero between calls
+    float2* split_part;    // [R * S] partial (max, sum)
 };
 
 static constexpr float kLog2e = 1.4426950408889634f;
@@ -212,61 +214,67 @@ __device__ __forceinline__ MaxSum block_combine(MaxSum a, float* s_m, float* s_s
     return r;
 }
 
+#ifdef MLS_STAMP
+// Diagnostic build only: phase timestamps (100 MHz counter) of the first 4096 workgroups.
+__device__ unsigned long long g_mls_stamps[4096 * 8];
+#define MSTAMP(n) do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_mls_stamps[blockIdx.x * 8 + (n)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+extern "C" __attribute__((visibility("default"))) int grx_debug_read_mls_stamps(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mls_stamps), sizeof(unsigned long long) * 4096 * 8);
+}
+#else
+#define MSTAMP(n) do { } while (0)
+#endif
+
 // ---- the kernel --------------------------------------------------------------
 // DT: element type of the logits.  OUT: OUT_*.  VEC: rows (and, for the full
 // modes, output rows) are 16-byte aligned so the stream uses 16-byte accesses;
 // otherwise one element per access.
-template <int DT, int OUT, bool VEC, int MODE>
+template <int DT, int OUT, bool VEC, bool SPLIT>
 __global__ __launch_bounds__(MLS_THREADS) void masked_lsm_kernel(MlsArgs a) {
     typedef Elem<DT> E;
     typedef typename E::T T;
     constexpr int EPV = VEC ? E::kPerVec : 1;  // elements per access
     __shared__ float s_m[MLS_WAVES], s_s[MLS_WAVES];
 
-    const int r = blockIdx.x;
+    const int r = SPLIT ? (int)blockIdx.x / a.S : (int)blockIdx.x;
+    const int part = SPLIT ? (int)blockIdx.x - r * a.S : 0;
     const int tid = threadIdx.x;
     const T* __restrict__ row = reinterpret_cast<const T*>(a.scores) + (int64_t)r * a.scores_stride;
+    MSTAMP(0);
 
     // The first batch of the stream is issued before anything else: the row
     // resolution below runs on scalar loads, which do not queue behind it.
     const int nvec = a.V / EPV;
+    int v_lo = 0, v_hi = nvec;  // this workgroup's share of the row's vectors
+    if (SPLIT) {
+        const int per = (nvec + a.S - 1) / a.S;
+        v_lo = part * per < nvec ? part * per : nvec;
+        v_hi = v_lo + per < nvec ? v_lo + per : nvec;
+    }
     const RowStream vp(row, (int64_t)nvec * 16);
     u32x4 v_head[MLS_UNROLL];
-    const bool head = VEC && (tid + (MLS_UNROLL - 1) * MLS_THREADS < nvec);
+    const bool head = VEC && (v_lo + tid + (MLS_UNROLL - 1) * MLS_THREADS < v_hi);
     if (head) {
 #pragma unroll
-        for (int u = 0; u < MLS_UNROLL; ++u) v_head[u] = vp.load(tid + u * MLS_THREADS);
+        for (int u = 0; u < MLS_UNROLL; ++u) v_head[u] = vp.load(v_lo + tid + u * MLS_THREADS);
     }
 
-    // Which trie node governs this row.  Every wave resolves it redundantly from
-    // wave-uniform addresses (a handful of cached loads), so the stream below can
-    // start without a workgroup barrier.
-    const int64_t* __restrict__ ids_row = a.ids + (int64_t)r * a.ids_stride;
-    int code;
-    if (MODE == GRX_MODE_COUNT) {
-        const int prev = (a.slot + 2) % 3;
-        int count = state_count_after(*a.st, prev);
-        if (r == 0 && tid == 0) {  // bookkeeping for the next call; no kernel of this call reads these words
-            a.st->count[a.slot] = count;
-            a.st->first_match[(a.slot + 1) % 3] = GRX_NO_MATCH;
-        }
-        if (a.pfx_n >= 0 && r >= a.st->first_match[a.slot]) count = 0;  // the shared counter was reset at or before this row
-        const int start = py_tail_start(a.prefix_index + count, a.T);
-        code = trie_walk(a.tv, ids_row + start, a.T - start);
-    } else {
-        code = resolve_fixed_row(a.tv, ids_row, a.T, a.pfx, a.eos, tid & (GRX_WAVE - 1));
+    // Which trie node governs this row: planned by the kernel that ran just before
+    // (one 16-byte scalar load, which does not queue behind the stream loads).
+    const grx_row_plan pl = a.plan[r];
+    int code = pl.code, c_off = pl.off, c_n = pl.n;
+    if (a.reset_aware && r >= a.st->first_match[a.slot] && pl.code0 != pl.code) {
+        // the shared counter was reset at or before this row (logit_processor.py:39-41)
+        code = pl.code0;
+        c_off = code >= 0 ? a.off[code] : 0;
+        c_n = code >= 0 ? a.off[code + 1] - c_off : (code == GRX_RES_EOS ? 1 : 0);
     }
-    int c_off = 0, c_n = 0;
-    if (code >= 0) {
-        c_off = a.tv.off[code];
-        c_n = a.tv.off[code + 1] - c_off;
-    } else if (code == GRX_RES_EOS) {
-        c_n = 1;
-    } else if (tid == 0) {
+    MSTAMP(1);
+    if (code < 0 && code != GRX_RES_EOS && tid == 0 && part == 0) {
         report_row_error(a.st, r, code == GRX_RES_NOMATCH ? GRX_ROWERR_NOMATCH : GRX_ROWERR_EMPTY);
     }
     if (OUT == OUT_COMPACT && c_n > a.cmax) {
-        if (tid == 0) report_row_error(a.st, r, GRX_ROWERR_OVERFLOW);
+        if (tid == 0 && part == 0) report_row_error(a.st, r, GRX_ROWERR_OVERFLOW);
         c_n = 0;
     }
 
@@ -274,20 +282,25 @@ __global__ __launch_bounds__(MLS_THREADS) void masked_lsm_kernel(MlsArgs a) {
     // thread belongs to compact entry e = tid + k * threads, i.e. candidate e - 1
     // (entry 0 is the row header), so that each store instruction of the epilogue
     // covers whole 128-byte lines.
+    // A split row is emitted by whichever workgroup finishes last, which gathers then.
     constexpr int SHIFT = (OUT == OUT_COMPACT) ? 1 : 0;
     int e_tok[MLS_EARLY];
     float e_val[MLS_EARLY];
+    auto gather = [&]() {
 #pragma unroll
-    for (int k = 0; k < MLS_EARLY; ++k) {
-        const int i = tid + k * MLS_THREADS - SHIFT;
-        e_tok[k] = -1;
-        e_val[k] = 0.f;
-        if (i >= 0 && i < c_n) {
-            e_tok[k] = (code == GRX_RES_EOS) ? a.eos : a.tv.tok[c_off + i];
-            e_val[k] = E::to_float(row[e_tok[k]]);
+        for (int k = 0; k < MLS_EARLY; ++k) {
+            const int i = tid + k * MLS_THREADS - SHIFT;
+            e_tok[k] = -1;
+            e_val[k] = 0.f;
+            if (i >= 0 && i < c_n) {
+                e_tok[k] = (code == GRX_RES_EOS) ? a.eos : a.tok[c_off + i];
+                e_val[k] = E::to_float(row[e_tok[k]]);
+            }
         }
-    }
+    };
+    if (!SPLIT) gather();
 
+    MSTAMP(2);
     // Stream the row once.
     MaxSum acc;
     acc.m = -INFINITY;
@@ -304,26 +317,26 @@ __global__ __launch_bounds__(MLS_THREADS) void masked_lsm_kernel(MlsArgs a) {
             accumulate<MLS_UNROLL * E::kPerVec>(acc, f);
         };
 
-        int i = tid;
+        int i = v_lo + tid;
         if (head) {
             consume(v_head, i);
             i += MLS_UNROLL * MLS_THREADS;
         }
-        for (; i + (MLS_UNROLL - 1) * MLS_THREADS < nvec; i += MLS_UNROLL * MLS_THREADS) {
+        for (; i + (MLS_UNROLL - 1) * MLS_THREADS < v_hi; i += MLS_UNROLL * MLS_THREADS) {
             u32x4 v[MLS_UNROLL];
 #pragma unroll
             for (int u = 0; u < MLS_UNROLL; ++u) v[u] = vp.load(i + u * MLS_THREADS);
             consume(v, i);
         }
-        for (; i < nvec; i += MLS_THREADS) {
+        for (; i < v_hi; i += MLS_THREADS) {
             const u32x4 v = vp.load(i);
             float f[E::kPerVec];
             E::unpack(v, f);
             accumulate<E::kPerVec>(acc, f);
         }
     }
-    // Elements not covered by 16-byte vectors (all of them when !VEC).
-    {
+    // Elements not covered by 16-byte vectors (all of them when !VEC); the last part of a split row.
+    if (!SPLIT || part == a.S - 1) {
         const float ninf_f = -INFINITY;
         for (int e = (VEC ? nvec * EPV : 0) + tid; e < a.V; e += MLS_THREADS) {
             float f[1] = {E::to_float(row[e])};
@@ -343,8 +356,51 @@ __global__ __launch_bounds__(MLS_THREADS) void masked_lsm_kernel(MlsArgs a) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     typedef typename std::conditional<OUT == OUT_FULL_F32, float, T>::type OT;
-    const MaxSum tot = block_combine(acc, s_m, s_s);  // contains a workgroup barrier
+    MSTAMP(3);
+    MaxSum tot = block_combine(acc, s_m, s_s);  // contains a workgroup barrier
+    MSTAMP(4);
+    if (SPLIT) {
+        // Publish this part; the workgroup that observes the S-th arrival owns the row.
+        // Partials and counters only ever move through device-scope atomics (which
+        // bypass the per-XCD L2), so no cache write-back or invalidate is needed.
+        __shared__ int s_last;
+        unsigned long long* parts = reinterpret_cast<unsigned long long*>(a.split_part) + (int64_t)r * a.S;
+        if (tid == 0) {
+            const unsigned long long packed =
+                ((unsigned long long)__float_as_uint(tot.s) << 32) | (unsigned long long)__float_as_uint(tot.m);
+            __hip_atomic_store(parts + part, packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the partial has landed before the arrival is counted
+            const int seen = __hip_atomic_fetch_add(&a.split_count[r], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = seen == a.S - 1;
+        }
+        __syncthreads();
+        if (!s_last) return;
+        float M = -INFINITY, sum = 0.f;
+        {
+            // lane p of every wave fetches partial p (S <= 32); merged in index order, so the
+            // result does not depend on which part came last
+            const int lane = tid & (GRX_WAVE - 1);
+            unsigned long long mine = 0;
+            if (lane < a.S) mine = __hip_atomic_load(parts + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int p = 0; p < a.S; ++p) {
+                const unsigned long long v = __shfl(mine, p, GRX_WAVE);
+                M = fmaxf(M, __uint_as_float((uint32_t)(v & 0xFFFFFFFFull)));
+            }
+            const float Mref = (M == -INFINITY) ? 0.f : M;
+            for (int p = 0; p < a.S; ++p) {
+                const unsigned long long v = __shfl(mine, p, GRX_WAVE);
+                sum += __uint_as_float((uint32_t)(v >> 32)) *
+                       fast_exp2((__uint_as_float((uint32_t)(v & 0xFFFFFFFFull)) - Mref) * kLog2e);
+            }
+        }
+        tot.m = M;
+        tot.s = sum;
+        if (tid == 0)  // ready for the next call
+            __hip_atomic_store(&a.split_count[r], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        gather();
+    }
     const float log_s = logf(tot.s);
+    MSTAMP(5);
 
     // Emit the allowed tokens.
     if (OUT == OUT_COMPACT) {
@@ -369,7 +425,7 @@ __global__ __launch_bounds__(MLS_THREADS) void masked_lsm_kernel(MlsArgs a) {
         for (int e = tid + MLS_EARLY * MLS_THREADS; e < n_line; e += MLS_THREADS) {
             grx_cand v = {0, 0};
             if (e - 1 < c_n) {
-                v.x = a.tv.tok[c_off + e - 1];  // an EOS-only row has c_n == 1 and never gets here
+                v.x = a.tok[c_off + e - 1];  // an EOS-only row has c_n == 1 and never gets here
                 v.y = __float_as_int((E::to_float(row[v.x]) - tot.m) - log_s);
             }
             cand_store(crow + e, v);
@@ -385,10 +441,14 @@ __global__ __launch_bounds__(MLS_THREADS) void masked_lsm_kernel(MlsArgs a) {
             if (i < c_n) put(e_tok[k], (e_val[k] - tot.m) - log_s);
         }
         for (int i = tid + MLS_EARLY * MLS_THREADS; i < c_n; i += MLS_THREADS) {
-            const int tok = a.tv.tok[c_off + i];  // an EOS-only row has c_n == 1 and never gets here
+            const int tok = a.tok[c_off + i];  // an EOS-only row has c_n == 1 and never gets here
             put(tok, (E::to_float(row[tok]) - tot.m) - log_s);
         }
     }
+#ifdef MLS_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    MSTAMP(6);
+#endif
 }
 
 // ---- dense output fill ---------------------------------------------------------
@@ -469,30 +529,35 @@ static int timing_slot() {
 // kernel only, no extra packets on the stream).
 template <typename KernelT>
 static void launch_one(KernelT kernel, const MlsArgs& a, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
+    const dim3 grid((unsigned)a.R * (unsigned)(a.S > 1 ? a.S : 1));
     if (ev0 || ev1)
-        hipExtLaunchKernelGGL(kernel, dim3(a.R), dim3(MLS_THREADS), 0, stream, ev0, ev1, 0, a);
+        hipExtLaunchKernelGGL(kernel, grid, dim3(MLS_THREADS), 0, stream, ev0, ev1, 0, a);
     else
-        hipLaunchKernelGGL(kernel, dim3(a.R), dim3(MLS_THREADS), 0, stream, a);
+        hipLaunchKernelGGL(kernel, grid, dim3(MLS_THREADS), 0, stream, a);
 }
 
 template <int DT, int OUT, bool VEC>
-static void launch_mode(int mode, const MlsArgs& a, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
-    if (mode == GRX_MODE_COUNT) launch_one(masked_lsm_kernel<DT, OUT, VEC, GRX_MODE_COUNT>, a, stream, ev0, ev1);
-    else launch_one(masked_lsm_kernel<DT, OUT, VEC, GRX_MODE_FIXED_HINT>, a, stream, ev0, ev1);
+static void launch_split(const MlsArgs& a, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
+    if constexpr (VEC) {  // only 16-byte streams are split
+        if (a.S > 1) {
+            launch_one(masked_lsm_kernel<DT, OUT, VEC, true>, a, stream, ev0, ev1);
+            return;
+        }
+    }
+    launch_one(masked_lsm_kernel<DT, OUT, VEC, false>, a, stream, ev0, ev1);
 }
 
 template <int DT, int OUT>
-static void launch_vec(bool vec, int mode, const MlsArgs& a, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
-    if (vec) launch_mode<DT, OUT, true>(mode, a, stream, ev0, ev1);
-    else launch_mode<DT, OUT, false>(mode, a, stream, ev0, ev1);
+static void launch_vec(bool vec, const MlsArgs& a, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
+    if (vec) launch_split<DT, OUT, true>(a, stream, ev0, ev1);
+    else launch_split<DT, OUT, false>(a, stream, ev0, ev1);
 }
 
 template <int OUT>
-static void launch_dtype(int dtype, bool vec, int mode, const MlsArgs& a, hipStream_t stream, hipEvent_t ev0,
-                         hipEvent_t ev1) {
-    if (dtype == GRX_F32) launch_vec<GRX_F32, OUT>(vec, mode, a, stream, ev0, ev1);
-    else if (dtype == GRX_BF16) launch_vec<GRX_BF16, OUT>(vec, mode, a, stream, ev0, ev1);
-    else launch_vec<GRX_F16, OUT>(vec, mode, a, stream, ev0, ev1);
+static void launch_dtype(int dtype, bool vec, const MlsArgs& a, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
+    if (dtype == GRX_F32) launch_vec<GRX_F32, OUT>(vec, a, stream, ev0, ev1);
+    else if (dtype == GRX_BF16) launch_vec<GRX_BF16, OUT>(vec, a, stream, ev0, ev1);
+    else launch_vec<GRX_F16, OUT>(vec, a, stream, ev0, ev1);
 }
 
 static size_t dtype_size(int dt) { return dt == GRX_F32 ? 4 : 2; }
@@ -508,27 +573,34 @@ static int run_step(const char* who, const grx_trie* trie, grx_state* state, con
     if (rc != GRX_OK) return rc;
     GRX_REQUIRE(con->eos_token_id < rows->V, GRX_E_INVALID, "%s: eos_token_id %d outside V=%d", who,
                 con->eos_token_id, rows->V);
-    a.slot = 0;
-    if (con->mode == GRX_MODE_COUNT) {
-        rc = grx_begin_count_call(state, rows, con, stream, &a.slot);
-        if (rc != GRX_OK) return rc;
-    }
+    // phase 0: one small kernel works out the trie node of every row
+    grx_row_plan* plan = rows->R > 0
+                             ? reinterpret_cast<grx_row_plan*>(reinterpret_cast<char*>(workspace) + GRX_WS_PLAN_OFFSET)
+                             : nullptr;
+    rc = grx_plan_rows(trie, state, rows, con, plan, stream, &a.slot);
+    if (rc != GRX_OK) return rc;
     if (rows->R == 0) return GRX_OK;
 
-    a.tv = TrieView{trie->child_off, trie->child_tok};
+    a.tok = trie->child_tok;
+    a.off = trie->child_off;
+    a.plan = plan;
     a.st = state ? state->dev : nullptr;
-    a.prefix_index = con->prefix_index;
-    a.pfx = grx_prefix_arg(con);
-    a.pfx_n = a.pfx.n;
-    a.ids = rows->input_ids;
-    a.ids_stride = rows->ids_stride;
-    a.T = rows->T;
+    a.reset_aware = (con->mode == GRX_MODE_COUNT && con->n_prefix >= 0) ? 1 : 0;
     a.R = rows->R;
     a.scores = rows->scores;
     a.scores_stride = rows->scores_stride;
     a.V = rows->V;
     a.eos = con->eos_token_id;
     const bool vec = rows_16b_aligned(rows->scores, rows->scores_stride, dtype_size(rows->dtype)) && out_aligned;
+    a.S = 1;
+    if (vec) {
+        const int S = grx_split_factor(rows->R, (int)(rows->V / (16 / dtype_size(rows->dtype))));
+        if (S > 1) {
+            a.S = S;
+            a.split_count = reinterpret_cast<int*>(workspace);
+            a.split_part = reinterpret_cast<float2*>(reinterpret_cast<char*>(workspace) + GRX_SPLIT_COUNT_BYTES);
+        }
+    }
     const int slot = timing_slot();
     hipEvent_t ev0 = slot >= 0 ? g_ev_start[slot] : nullptr, ev1 = slot >= 0 ? g_ev_stop[slot] : nullptr;
     if (out_kind != OUT_COMPACT && vec) {
@@ -554,9 +626,9 @@ static int run_step(const char* who, const grx_trie* trie, grx_state* state, con
         ev0 = nullptr;
 
     }
-    if (out_kind == OUT_COMPACT) launch_dtype<OUT_COMPACT>(rows->dtype, vec, con->mode, a, stream, ev0, ev1);
-    else if (out_kind == OUT_FULL_F32) launch_dtype<OUT_FULL_F32>(rows->dtype, vec, con->mode, a, stream, ev0, ev1);
-    else launch_dtype<OUT_FULL_SAME>(rows->dtype, vec, con->mode, a, stream, ev0, ev1);
+    if (out_kind == OUT_COMPACT) launch_dtype<OUT_COMPACT>(rows->dtype, vec, a, stream, ev0, ev1);
+    else if (out_kind == OUT_FULL_F32) launch_dtype<OUT_FULL_F32>(rows->dtype, vec, a, stream, ev0, ev1);
+    else launch_dtype<OUT_FULL_SAME>(rows->dtype, vec, a, stream, ev0, ev1);
     GRX_CHECK_HIP(hipGetLastError());
     if (slot >= 0) g_timing_n = slot + 1;
     return GRX_OK;

@@ -5,12 +5,35 @@
 
 PrefixArg grx_prefix_arg(const grx_constraint* con);
 
-// Open a count-based processor call on `stream`: picks the state slot the call
-// owns, enqueues the scan for rows that end in prefix_ids (when prefix_ids is
-// given) and advances the host-side call counter.  With no rows it only moves
-// the counter forward.
-int grx_begin_count_call(grx_state* state, const grx_rows* rows, const grx_constraint* con, hipStream_t stream,
-                         int* slot_out);
+// Plan of one row for the streaming kernel: the governing trie node (or a negative
+// GRX_RES_* code), its child range, and the node of the row's count == 0 window.
+struct grx_row_plan {
+    int32_t code;
+    int32_t off;
+    int32_t n;
+    int32_t code0;
+};
+
+// Open a processor call on `stream`: picks the state slot a count-based call owns,
+// advances the host-side call counter and enqueues the kernel that writes one
+// grx_row_plan per row (and, count-based, finds the rows that end in prefix_ids).
+int grx_plan_rows(const grx_trie* trie, grx_state* state, const grx_rows* rows, const grx_constraint* con,
+                  grx_row_plan* plan, hipStream_t stream, int* slot_out);
 
 int grx_check_step_args(const char* who, const grx_trie* trie, const grx_state* state, const grx_rows* rows,
                         const grx_constraint* con, const void* workspace, size_t workspace_bytes);
+
+// Split rows.  With few rows, one workgroup per row leaves most of the chip idle,
+// so a row is streamed by S workgroups (S a power of two, R * S <= GRX_SPLIT_MAX_PARTS).
+// The merge costs about 10 us of device-scope atomics, which only pays below a few
+// hundred rows (measured: 256 rows 25.8 -> 19.6 us, 16 rows 23.6 -> 14.7 us, 512 rows slower).
+// The caller's workspace holds the arrival counters ([GRX_SPLIT_MAX_ROWS] int32, zero
+// between calls) followed by the partial (max, sum) pairs; the row plans come after them.
+#define GRX_SPLIT_MAX_ROWS 256
+#define GRX_SPLIT_MAX_PARTS 2048
+#define GRX_SPLIT_COUNT_BYTES (GRX_SPLIT_MAX_ROWS * 4)
+#define GRX_WS_PLAN_OFFSET (GRX_SPLIT_COUNT_BYTES + GRX_SPLIT_MAX_PARTS * 8)
+int grx_split_factor(int R, int row_vecs);
+
+// Device view of a trie handle for kernel arguments.
+TrieView grx_trie_view(const grx_trie* trie);

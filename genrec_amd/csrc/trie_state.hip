@@ -50,7 +50,30 @@ extern "C" int grx_trie_create(const int32_t* child_off, const int32_t* child_to
     t->n_edges = n_edges;
     t->max_fanout = max_fanout;
     t->max_token = max_token;
+    // unary chain below the root
+    t->chain_n = 0;
+    t->chain_node = 0;
+    while (t->chain_n < GRX_CHAIN_MAX && child_off[t->chain_node + 1] - child_off[t->chain_node] == 1) {
+        const int32_t edge = child_off[t->chain_node];
+        t->chain_tok[t->chain_n++] = child_tok[edge];
+        t->chain_node = edge + 1;
+    }
+    // edge table: power-of-two size >= 2 * n_edges, linear probing
+    uint32_t slots = 16;
+    while (slots < 2u * (uint32_t)n_edges) slots <<= 1;
+    t->hash_mask = slots - 1;
+    std::vector<grx_edge_slot> table(slots, grx_edge_slot{-1, -1, -1, 0});
+    for (int32_t n = 0; n < n_nodes; ++n) {
+        for (int32_t e = child_off[n]; e < child_off[n + 1]; ++e) {
+            uint32_t h = grx_edge_hash((uint32_t)n, (uint32_t)child_tok[e]) & t->hash_mask;
+            while (table[h].parent >= 0) h = (h + 1) & t->hash_mask;
+            table[h] = grx_edge_slot{n, child_tok[e], e + 1, 0};
+        }
+    }
     hipError_t e = hipGetDevice(&t->device);
+    if (e == hipSuccess) e = hipMalloc((void**)&t->edge_hash, sizeof(grx_edge_slot) * (size_t)slots);
+    if (e == hipSuccess)
+        e = hipMemcpy(t->edge_hash, table.data(), sizeof(grx_edge_slot) * (size_t)slots, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc((void**)&t->child_off, sizeof(int32_t) * (size_t)(n_nodes + 1));
     if (e == hipSuccess) e = hipMalloc((void**)&t->child_tok, sizeof(int32_t) * (size_t)(n_edges > 0 ? n_edges : 1));
     if (e == hipSuccess)
@@ -61,6 +84,7 @@ extern "C" int grx_trie_create(const int32_t* child_off, const int32_t* child_to
         grx_set_error("grx_trie_create: %s", hipGetErrorString(e));
         if (t->child_off) (void)hipFree(t->child_off);
         if (t->child_tok) (void)hipFree(t->child_tok);
+        if (t->edge_hash) (void)hipFree(t->edge_hash);
         delete t;
         return GRX_E_HIP;
     }
@@ -72,6 +96,7 @@ extern "C" int grx_trie_destroy(grx_trie* t) {
     if (!t) return GRX_OK;
     (void)hipFree(t->child_off);
     (void)hipFree(t->child_tok);
+    (void)hipFree(t->edge_hash);
     delete t;
     return GRX_OK;
 }
@@ -157,18 +182,58 @@ extern "C" int grx_state_read(grx_state* s, int32_t out[4], void* stream) {
     return GRX_OK;
 }
 
-// ------------------------------------------------------------ match scan ---
-// Lowest row whose last prefix_index tokens equal prefix_ids
-// (logit_processor.py:39-40): from that row on the shared counter is 0.
-__global__ void match_scan_kernel(grx_state_words* st, int slot, const int64_t* __restrict__ ids, int64_t ids_stride,
-                                  int R, int T, PrefixArg pfx, int prefix_index) {
+// ------------------------------------------------------------- row plans ---
+// Which trie node governs each row, worked out ahead of the streaming kernel so
+// that kernel starts streaming after a single 16-byte load per row.
+//
+// Count-based mode (logit_processor.py:38-44), one thread per row: the window is
+// the last prefix_index + count tokens, where count is the shared counter after
+// the previous call.  Rows whose last prefix_index tokens equal prefix_ids reset
+// the shared counter for themselves and every later row (logit_processor.py:39-40);
+// the lowest such row is min-reduced into first_match[slot], and every row also
+// gets the node of its count == 0 window (code0) for the streaming kernel to pick.
+__global__ void plan_count_rows_kernel(grx_state_words* st, int slot, TrieView tv, const int64_t* __restrict__ ids,
+                                       int64_t ids_stride, int R, int T, PrefixArg pfx, int prefix_index,
+                                       grx_row_plan* __restrict__ plan) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= R) return;
+    const int prev = (slot + 2) % 3;
+    const int count = state_count_after(*st, prev);
+    if (r == 0) {  // bookkeeping for the next call; no kernel of this call reads these words
+        st->count[slot] = count;
+        st->first_match[(slot + 1) % 3] = GRX_NO_MATCH;
+    }
     const int64_t* row = ids + (int64_t)r * ids_stride;
     const int s0 = py_tail_start(prefix_index, T);
-    bool match = (T - s0) == pfx.n;
-    for (int i = 0; match && i < pfx.n; ++i) match = row[s0 + i] == pfx.ids[i];
-    if (match) atomicMin(&st->first_match[slot], r);
+    if (pfx.n >= 0) {
+        bool match = (T - s0) == pfx.n;
+        for (int i = 0; match && i < pfx.n; ++i) match = row[s0 + i] == pfx.ids[i];
+        if (match) atomicMin(&st->first_match[slot], r);
+    }
+    const int start = py_tail_start(prefix_index + count, T);
+    grx_row_plan pl;
+    pl.code = trie_walk(tv, row + start, T - start);
+    pl.off = pl.code >= 0 ? tv.off[pl.code] : 0;
+    pl.n = pl.code >= 0 ? tv.off[pl.code + 1] - pl.off : 0;
+    pl.code0 = (pfx.n >= 0 && start != s0) ? trie_walk(tv, row + s0, T - s0) : pl.code;
+    plan[r] = pl;
+}
+
+// Fixed-hint mode (fixed_hint_logit_processor.py:43-61), one wave per row.
+__global__ void plan_fixed_rows_kernel(TrieView tv, const int64_t* __restrict__ ids, int64_t ids_stride, int R, int T,
+                                       PrefixArg pfx, int eos, grx_row_plan* __restrict__ plan) {
+    const int lane = threadIdx.x & (GRX_WAVE - 1);
+    const int r = (blockIdx.x * blockDim.x + threadIdx.x) / GRX_WAVE;
+    if (r >= R) return;
+    const int code = resolve_fixed_row(tv, ids + (int64_t)r * ids_stride, T, pfx, eos, lane);
+    if (lane == 0) {
+        grx_row_plan pl;
+        pl.code = code;
+        pl.off = code >= 0 ? tv.off[code] : 0;
+        pl.n = code >= 0 ? tv.off[code + 1] - pl.off : (code == GRX_RES_EOS ? 1 : 0);
+        pl.code0 = code;
+        plan[r] = pl;
+    }
 }
 
 // Bookkeeping of a count-based call that has no rows to process.
@@ -179,8 +244,29 @@ __global__ void state_bookkeeping_kernel(grx_state_words* st, int slot) {
 }
 
 extern "C" size_t grx_workspace_bytes(int32_t R) {
-    (void)R;
-    return 256;  // the current kernels keep all per-row state in registers and LDS
+    const size_t rows = R > 0 ? (size_t)R : 0;
+    return GRX_WS_PLAN_OFFSET + rows * sizeof(grx_row_plan);
+}
+
+// Number of workgroups that share one row: enough to fill the 256 CUs eight deep,
+// while every thread still streams at least two 16-byte vectors.
+int grx_split_factor(int R, int row_vecs) {
+    if (R <= 0 || R > GRX_SPLIT_MAX_ROWS) return 1;
+    int S = 1;
+    while (S < 32 && R * (S * 2) <= GRX_SPLIT_MAX_PARTS && row_vecs / (S * 2) >= 512) S *= 2;
+    return S;
+}
+
+TrieView grx_trie_view(const grx_trie* trie) {
+    TrieView tv;
+    tv.off = trie->child_off;
+    tv.tok = trie->child_tok;
+    tv.hash = trie->edge_hash;
+    tv.hash_mask = trie->hash_mask;
+    tv.chain_n = trie->chain_n;
+    tv.chain_node = trie->chain_node;
+    for (int i = 0; i < GRX_CHAIN_MAX; ++i) tv.chain_tok[i] = i < trie->chain_n ? trie->chain_tok[i] : -1;
+    return tv;
 }
 
 PrefixArg grx_prefix_arg(const grx_constraint* con) {
@@ -191,22 +277,31 @@ PrefixArg grx_prefix_arg(const grx_constraint* con) {
     return pfx;
 }
 
-// Open a count-based call: returns its slot and enqueues the prefix match scan.
-int grx_begin_count_call(grx_state* state, const grx_rows* rows, const grx_constraint* con, hipStream_t stream,
-                         int* slot_out) {
-    const int slot = (int)(state->calls % 3u);
-    *slot_out = slot;
-    if (rows->R == 0) {
-        hipLaunchKernelGGL(state_bookkeeping_kernel, dim3(1), dim3(1), 0, stream, state->dev, slot);
+// Open a processor call on `stream`: in the count-based mode pick the state slot the
+// call owns and advance the host-side call counter; enqueue the row planning kernel.
+int grx_plan_rows(const grx_trie* trie, grx_state* state, const grx_rows* rows, const grx_constraint* con,
+                  grx_row_plan* plan, hipStream_t stream, int* slot_out) {
+    *slot_out = 0;
+    const int threads = 256;
+    if (con->mode == GRX_MODE_COUNT) {
+        const int slot = (int)(state->calls % 3u);
+        *slot_out = slot;
+        if (rows->R == 0) {
+            hipLaunchKernelGGL(state_bookkeeping_kernel, dim3(1), dim3(1), 0, stream, state->dev, slot);
+        } else {
+            hipLaunchKernelGGL(plan_count_rows_kernel, dim3((rows->R + threads - 1) / threads), dim3(threads), 0,
+                               stream, state->dev, slot, grx_trie_view(trie), rows->input_ids, rows->ids_stride,
+                               rows->R, rows->T, grx_prefix_arg(con), con->prefix_index, plan);
+        }
         GRX_CHECK_HIP(hipGetLastError());
-    } else if (con->n_prefix >= 0) {
-        const int threads = 256;
-        hipLaunchKernelGGL(match_scan_kernel, dim3((rows->R + threads - 1) / threads), dim3(threads), 0, stream,
-                           state->dev, slot, rows->input_ids, rows->ids_stride, rows->R, rows->T, grx_prefix_arg(con),
-                           con->prefix_index);
+        state->calls += 1;
+    } else if (rows->R > 0) {
+        const int64_t total = (int64_t)rows->R * GRX_WAVE;
+        hipLaunchKernelGGL(plan_fixed_rows_kernel, dim3((unsigned)((total + threads - 1) / threads)), dim3(threads), 0,
+                           stream, grx_trie_view(trie), rows->input_ids, rows->ids_stride, rows->R, rows->T,
+                           grx_prefix_arg(con), con->eos_token_id, plan);
         GRX_CHECK_HIP(hipGetLastError());
     }
-    state->calls += 1;
     return GRX_OK;
 }
 
@@ -228,8 +323,10 @@ int grx_check_step_args(const char* who, const grx_trie* trie, const grx_state* 
                     "%s: null input_ids/scores", who);
         GRX_REQUIRE(rows->ids_stride >= rows->T && rows->scores_stride >= rows->V, GRX_E_INVALID,
                     "%s: row stride smaller than the row", who);
-        (void)workspace;  // reserved: the current kernels need no device scratch
-        (void)workspace_bytes;
+        GRX_REQUIRE(workspace != nullptr && ((uintptr_t)workspace & 15u) == 0, GRX_E_WORKSPACE,
+                    "%s: a 16-byte aligned workspace is required", who);
+        GRX_REQUIRE(workspace_bytes >= grx_workspace_bytes(rows->R), GRX_E_WORKSPACE,
+                    "%s: workspace of %zu bytes, need %zu", who, workspace_bytes, grx_workspace_bytes(rows->R));
     }
     GRX_REQUIRE(trie->max_token < rows->V, GRX_E_INVALID,
                 "%s: the trie holds token id %d but rows have only V=%d columns", who, trie->max_token, rows->V);

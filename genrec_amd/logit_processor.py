@@ -114,7 +114,7 @@ class _TrieConstrainedBase(LogitsProcessor):
         self.sync_errors = _eager_errors_default() if sync_errors is None else bool(sync_errors)
         self._trie: Optional[FlatTrie] = None
         self._states: dict[int, _DeviceState] = {}
-        self._workspaces: dict[tuple[int, int], torch.Tensor] = {}
+        self._workspaces: dict[int, torch.Tensor] = {}
         self._active: Optional[int] = None  # device index of the last call
 
     # -- trie ---------------------------------------------------------------------
@@ -138,12 +138,13 @@ class _TrieConstrainedBase(LogitsProcessor):
         pass
 
     def _workspace(self, index: int, rows: int) -> torch.Tensor:
-        key = (index, rows)
+        key = index
         ws = self._workspaces.get(key)
-        if ws is None:
-            nbytes = int(_lib.lib().grx_workspace_bytes(rows))
-            ws = torch.empty(nbytes, dtype=torch.uint8, device=torch.device("cuda", index))
-            self._workspaces = {key: ws}  # keep only the latest shape
+        nbytes = int(_lib.lib().grx_workspace_bytes(rows))
+        if ws is None or ws.numel() < nbytes:
+            # zero-filled once; the kernels hand it back zero-filled after every call
+            ws = torch.zeros(nbytes, dtype=torch.uint8, device=torch.device("cuda", index))
+            self._workspaces[key] = ws
         return ws
 
     def _constraint(self) -> _lib.GrxConstraint:

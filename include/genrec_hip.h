@@ -122,8 +122,14 @@ typedef struct grx_constraint {
     int64_t prefix_ids[GRX_MAX_PREFIX];
 } grx_constraint;
 
-/* bytes of device scratch the two calls below want for R rows (reserved: the
- * current kernels keep per-row state in registers and LDS and ask for 256) */
+/* Bytes of device scratch the two calls below need for R rows (required when
+ * R > 0).  It holds the per-row plans a small kernel writes ahead of the
+ * streaming kernel (the trie node that governs each row), and the arrival
+ * counters and partial (max, sum) pairs of rows that are streamed by several
+ * workgroups (launches of few rows).  It must be 16-byte aligned and ZERO-FILLED
+ * when first handed over; every call leaves the counters zero-filled again, so
+ * one buffer serves all calls of a stream.  Calls that share a workspace must not
+ * overlap. */
 GRX_API size_t grx_workspace_bytes(int32_t R);
 
 /*

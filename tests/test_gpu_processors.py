@@ -307,6 +307,53 @@ def test_caller_owned_output_padded_rows_and_fp32_results(dtype):
         proc(ids, scores, out=torch.empty((R, V), dtype=torch.float16, device=dev))
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_few_rows_are_split_across_workgroups_with_the_same_results(dtype):
+    """Launches of few rows stream each row with several workgroups and merge partial (max, sum)
+    pairs; the same rows inside a large launch take the one-workgroup path.  Tokens are identical,
+    log-probs agree to rounding and with float64, and back-to-back calls of different sizes share
+    one scratch buffer."""
+    from genrec_amd.logit_processor import ConstrainedLogitsProcessor
+    from genrec_amd.synth import ASSISTANT_PREFIX, SidTokenizer, sample_decode_rows
+    from genrec_amd.trie import build_trie_from_index, create_prefix_allowed_tokens_fn
+    from helpers import write_index_file
+    import tempfile
+
+    dev = _dev()
+    path = write_index_file("Instruments", tempfile.mkdtemp())
+    tok = SidTokenizer.from_index(path)
+    trie, suffix, pidx = build_trie_from_index(path, tok, prefix=ASSISTANT_PREFIX)
+    fn = create_prefix_allowed_tokens_fn(trie, suffix)
+    V, K = tok.vocab_size_padded, 16
+    proc = ConstrainedLogitsProcessor(fn, K, pidx, None, tok.eos_token_id, sync_errors=True)
+    big_ids = torch.from_numpy(sample_decode_rows(trie, 32, K, 2, seed=9)).to(dev)      # 512 rows: not split
+    torch.manual_seed(11)
+    big = (torch.randn(512, V, device=dev) * 4).to(dtype)
+    big[3, 17] = 60.0  # a dominant logit far from the row's allowed tokens
+    proc.count = 2
+    want = proc.candidates(big_ids, big)
+    exact = torch.logsumexp(big.double(), dim=-1)
+    assert float((want.logsumexp.double() - exact).abs().max()) <= FP32_TOL
+    for R in (256, 16, 64, 16):  # descending and ascending: the shared scratch is left clean every time
+        proc.count = 2
+        got = proc.candidates(big_ids[:R], big[:R])
+        assert torch.equal(got.count, want.count[:R])
+        valid = torch.arange(got.cmax, device=dev)[None, :] < got.count[:, None]
+        assert torch.equal(got.tokens[valid], want.tokens[:R][valid])
+        assert float((got.logsumexp.double() - exact[:R]).abs().max()) <= FP32_TOL
+        assert float((got.logp[valid] - want.logp[:R][valid]).abs().max()) <= 4e-6
+        proc.count = 2
+        dense = proc(big_ids[:R], big[:R])
+        fin = torch.isfinite(dense)
+        assert torch.equal(fin.sum(dim=1).int(), want.count[:R])
+        ref = want.logp[:R][valid]
+        err = (dense[fin].float() - ref).abs()
+        if dtype == torch.float32:
+            assert float(err.max()) <= 4e-6
+        else:  # one bf16 rounding of the fp32 value: half an ulp = 2^-9 relative
+            assert bool((err <= ref.abs() * 2.0 ** -8 + 1e-6).all())
+
+
 def test_strided_inputs_and_unnormalised_extremes():
     """Non-contiguous views, very peaked rows and rows containing -inf."""
     from oracle.processors import DictTrie, RefFixedHintConstrainedLogitsProcessor

@@ -55,7 +55,7 @@ def main():
                                  trie.n_nodes, trie.n_edges, C.byref(t)) == 0
         st = C.c_void_p()
         assert h.grx_state_create(C.byref(st)) == 0
-        ws = torch.empty(int(h.grx_workspace_bytes(R)), dtype=torch.uint8, device=dev)
+        ws = torch.zeros(int(h.grx_workspace_bytes(R)), dtype=torch.uint8, device=dev)
         libs[name] = (h, t, st, ws)
     rows = _lib.GrxRows()
     rows.input_ids, rows.ids_stride, rows.R, rows.T = ids.data_ptr(), ids.stride(0), R, ids.shape[1]
