@@ -172,6 +172,47 @@ def time_cpu_baseline(args, wl):
     }
 
 
+def time_processor_surface(args, wl, device, calls=10):
+    """The unmodified-HF-loop form of the step: processor(input_ids, scores) -> dense [R, V] result
+    (fill kernel + stream kernel), timed by the library's dispatch events.  Algorithmic bytes are
+    input once + output once.  Not part of `value`."""
+    import ctypes as C
+
+    import torch
+
+    from genrec_amd import _lib
+    from genrec_amd.synth import sample_decode_rows
+
+    lib = _lib.lib()
+    proc = wl["proc"]
+    R, V = args.batch * args.beams, wl["V"]
+    ids = torch.from_numpy(sample_decode_rows(wl["trie"], args.batch, args.beams, 1, prompt_len=args.prompt_len,
+                                              seed=5)).to(device)
+    out = {}
+    for name, x in (("bf16->bf16", wl["logits"][1]), ("fp32->fp32", None)):
+        if x is None:
+            x = wl["logits"][1].float()
+        res = torch.empty_like(x)
+        for i in range(calls + 2):
+            if i == 2:
+                torch.cuda.synchronize()
+                lib.grx_timing_enable(1)
+            if hasattr(proc, "reset"):
+                proc.count = 1
+            proc(ids, x, out=res)
+        torch.cuda.synchronize()
+        tot, n = C.c_double(), C.c_int32()
+        _lib.check(lib.grx_timing_read(C.byref(tot), C.byref(n)))
+        lib.grx_timing_enable(0)
+        ms = tot.value / max(n.value, 1)
+        nbytes = 2 * R * V * x.element_size()
+        out[name] = {"ms_per_call": ms, "algorithmic_bytes": nbytes, "achieved_GBps": nbytes / ms / 1e6,
+                     "frac_of_peak": nbytes / ms / 1e6 / HBM_PEAK_GBS}
+        del res, x
+    proc.check_errors()
+    return out
+
+
 def recorded_traffic(args, alg_bytes):
     """HBM bytes per launch of the dominant kernel from hardware counters.
 
@@ -211,6 +252,7 @@ def main() -> None:
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--cpu-groups", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-processor-surface", action="store_true", help="skip the dense [R, V] mode measurement")
     ap.add_argument("--no-kernel-timing", action="store_true", help="leave the per-launch HIP events out")
     args = ap.parse_args()
 
@@ -307,6 +349,8 @@ def main() -> None:
                 "launches_timed": n.value,
             },
         }
+        if world == 1 and not args.no_processor_surface:
+            out["processor_surface"] = time_processor_surface(args, wl, device)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = time_cpu_baseline(args, wl)
         print(json.dumps(out), flush=True)
