@@ -43,3 +43,43 @@ def write_index_file(name: str, directory) -> str:
 def live(scores, threshold: float = -1.0e8):
     """Mask of beam slots that are not -1e9 placeholders / -inf fillers."""
     return scores > threshold
+
+
+# ---------------------------------------------------------------- cascade scenarios ---
+CASCADE_LETTERS = "abcdefgh"
+CASCADE_CODES = 12
+
+
+def cascade_tokenizer(levels: int):
+    """SidTokenizer over <a_0>..<a_11>, <b_0>.. for the cascade scenarios."""
+    from genrec_amd.synth import SidTokenizer
+
+    return SidTokenizer(f"<{CASCADE_LETTERS[l]}_{c}>" for l in range(levels) for c in range(CASCADE_CODES))
+
+
+def cascade_case_tensors(case, device, prompt_len: int = 7, seed: int = 0):
+    """Token tensors of one golden cascade scenario: prompts [G, T], gt [G, L], per-group depth caps,
+    and ``table[(g, d)]`` -> completions [K, L + 1] (item tokens, EOS, padding)."""
+    import torch
+
+    from genrec_amd.synth import ASSISTANT_PREFIX_IDS
+    from oracle.cascade import group_max_depth
+
+    L, K = case["L"], case["K"]
+    tok = cascade_tokenizer(L)
+
+    def ids(codes, start):
+        return [tok.encode(f"<{CASCADE_LETTERS[start + i]}_{c}>")[0] for i, c in enumerate(codes)]
+
+    g = torch.Generator().manual_seed(seed)
+    G = len(case["gts"])
+    prompts = torch.cat([torch.randint(0, 150000, (G, prompt_len), generator=g),
+                         torch.tensor([ASSISTANT_PREFIX_IDS] * G)], dim=1).to(device)
+    gt = torch.tensor([ids(c, 0) for c in case["gts"]], dtype=torch.int64, device=device)
+    caps = torch.tensor([group_max_depth(o, case["max_depth"]) for o in case["overrides"]], dtype=torch.int32,
+                        device=device)
+    table = {}
+    for grp, d, comps in case["table"]:
+        rows = [ids(c, d) + [tok.eos_token_id] + [tok.pad_token_id] * d for c in comps]
+        table[(grp, d)] = torch.tensor(rows, dtype=torch.int64, device=device)
+    return tok, prompts, gt, caps, table

@@ -171,3 +171,46 @@ def test_group_advantages_match_oracle_and_docs():
     assert torch.allclose(got, want, atol=1e-4)
     pen = ndcg_rank_penalties(8, 4, dev, process_index=1).cpu()
     assert [round(float(x), 4) for x in pen] == [-0.3904, -0.2463, -0.1952, -0.1681] * 2
+
+
+def test_dynamic_hint_cascade_makes_the_reference_decisions(monkeypatch):
+    """The device cascade (hinted prompts by indexing, rule hits from the reward kernel, masked
+    selection) reproduces the decisions recorded from the reference's _run_dynamic_hint_cascade."""
+    from helpers import cascade_case_tensors, load_json_gz
+
+    import genrec_amd.cascade as cascade
+    from genrec_amd.rewards.ranking_reward import SidRewardScorer
+
+    dev = _dev()
+    for n, case in enumerate(load_json_gz("cascade.json.gz")["cases"]):
+        tok, prompts, gt, caps, table = cascade_case_tensors(case, dev, seed=n)
+        K, L, want = case["K"], case["L"], case["expected"]
+        scorer = SidRewardScorer(tok.code_table(), K, dev)
+        calls, stage = [], [0]
+
+        def generate(stage_prompts, depths, groups):
+            T = prompts.shape[1]
+            for row, g, d in zip(stage_prompts.tolist(), groups.tolist(), depths.tolist()):
+                width = len(row)
+                assert row[width - T - d:] == prompts[g].tolist() + gt[g, :d].tolist()
+                assert all(t == tok.pad_token_id for t in row[: width - T - d])
+            calls.append({"groups": groups.tolist(), "depths": depths.tolist()})
+            return torch.cat([table[(g, d)] for g, d in zip(groups.tolist(), depths.tolist())], 0)
+
+        def others(n_left, device, group=None):  # the scripted state of the other ranks
+            flag = case["others"][stage[0]] if case["others"] is not None else False
+            stage[0] += 1
+            return n_left > 0 or flag
+
+        monkeypatch.setattr(cascade, "any_rank_unresolved", others)
+        got = cascade.run_dynamic_hint_cascade(generate, prompts, gt, K, case["max_depth"], scorer,
+                                               tok.pad_token_id, depth_cap=caps)
+        assert got.hint_depth.tolist() == want["selected_group_hint_depths"]
+        assert got.prompt_hint_depth.tolist() == want["selected_prompt_hint_depths"]
+        assert got.rule_hit_any.tolist() == want["selected_group_rule_hits"]
+        assert got.rule_rewards.tolist() == want["selected_rule_rewards"]
+        assert got.stage_stats == want["stage_stats"]
+        assert calls == want["calls"]
+        codes = tok.code_table()
+        rows = [[int(codes[t]) for t in row if codes[t] >= 0] for row in got.completion_ids.tolist()]
+        assert rows == want["selected_completions"]

@@ -191,3 +191,17 @@ def test_metrics_from_histogram_matches_oracle():
     got = metrics_from_histogram(hist, len(data), n_beam)
     want = ref_compute_metrics(data)
     assert set(got) == set(want) and all(abs(got[k] - want[k]) < 1e-12 for k in want)
+
+
+def test_cascade_hinted_prompts_are_left_padded_prompt_plus_hint():
+    import torch
+
+    from genrec_amd.cascade import hinted_prompts
+
+    prompts = torch.tensor([[5, 6, 7], [8, 9, 10]])
+    gt = torch.tensor([[101, 102, 103, 104], [201, 202, 203, 204]])
+    rows = hinted_prompts(prompts, gt, torch.tensor([0, 2], dtype=torch.int32), 3 + 3, 0)
+    assert rows.tolist() == [[0, 0, 0, 5, 6, 7], [0, 8, 9, 10, 201, 202]]
+    rows = hinted_prompts(prompts, gt, torch.tensor([3, 1], dtype=torch.int32), 3 + 3, 0)
+    assert rows.tolist() == [[5, 6, 7, 101, 102, 103], [0, 0, 8, 9, 10, 201]]
+    assert hinted_prompts(prompts, gt, torch.tensor([0, 0], dtype=torch.int32), 3, 0).tolist() == prompts.tolist()

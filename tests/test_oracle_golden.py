@@ -200,3 +200,28 @@ def test_docs_worked_examples():
                          [-0.1473] * 4])
     assert torch.allclose(tok_adv, want, atol=1e-4)
     assert math.isclose(float(oscore.ref_ndcg_rank_penalties(8, 4, 1)[5]), -0.2463, abs_tol=1e-4)
+
+
+def test_cascade_oracle_matches_reference_golden():
+    """The dynamic-hint cascade restatement makes the reference's decisions on every recorded scenario
+    (tests/golden/make_golden_cascade.py drove the reference's own method)."""
+    from oracle import cascade as ocascade
+
+    cases = load_json_gz("cascade.json.gz")["cases"]
+    assert len(cases) >= 30
+    multi = 0
+    for case in cases:
+        table = {(g, d): comps for g, d, comps in case["table"]}
+        out = ocascade.run_cascade(case["gts"], case["overrides"], case["K"], case["max_depth"],
+                                   lambda groups, depths: [table[(g, d)] for g, d in zip(groups, depths)],
+                                   case["others"])
+        want = case["expected"]
+        assert out["selected_group_hint_depths"] == want["selected_group_hint_depths"]
+        assert out["selected_group_rule_hits"] == want["selected_group_rule_hits"]
+        assert [r for s in out["selected"] for r in s["rule_rewards"]] == want["selected_rule_rewards"]
+        assert [c for s in out["selected"] for c in s["completions"]] == want["selected_completions"]
+        assert [s["prompt_hint_depth"] for s in out["selected"]] == want["selected_prompt_hint_depths"]
+        assert out["stage_stats"] == want["stage_stats"]
+        assert [{"groups": c["groups"], "depths": c["depths"]} for c in out["calls"]] == want["calls"]
+        multi += case["others"] is not None
+    assert multi >= 8  # scenarios in which other ranks keep the cascade running
