@@ -69,6 +69,8 @@ class GrxConstraint(C.Structure):
         ("n_prefix", C.c_int32),
         ("eos_token_id", C.c_int32),
         ("prefix_ids", C.c_int64 * GRX_MAX_PREFIX),
+        ("repetition_penalty", C.c_float),
+        ("penalty_skip", C.c_int32),
     ]
 
 

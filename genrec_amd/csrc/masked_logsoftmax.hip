@@ -25,6 +25,8 @@
 #define MLS_NT 1          // 1: non-temporal loads for the logit stream (each byte is read once)
 #endif
 #define MLS_EARLY (512 / MLS_THREADS > 0 ? 512 / MLS_THREADS : 1)  // allowed tokens gathered per thread up front
+#define PEN_SLOT_BITS 12
+#define PEN_SLOTS (1 << PEN_SLOT_BITS)  // open-addressing set of the penalised tokens of a row (<= 1536 tokens)
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
@@ -49,6 +51,12 @@ struct MlsArgs {
     int cmax;
     // Split rows (few rows): a row is streamed by S workgroups; the last one to
     // finish merges the S partial (max, sum) pairs and emits the row.
+    // Repetition penalty (0: off) over the tokens of ids[r, pen_from:T).
+    float penalty;
+    int pen_from;
+    const int64_t* ids;
+    int64_t ids_stride;
+    int T;
     int S;
     int* split_count;      // [R] arrival counters, zero between calls
     float2* split_part;    // [R * S] partial (max, sum)
@@ -402,6 +410,76 @@ __global__ __launch_bounds__(MLS_THREADS) void masked_lsm_kernel(MlsArgs a) {
     const float log_s = logf(tot.s);
     MSTAMP(5);
 
+    // Optional repetition penalty, applied where transformers applies it: on
+    // y = log_softmax(row), y_v <- y_v * p (y_v < 0) or y_v / p for every token v that
+    // occurs in the row's ids; the result is normalised again.  Only the penalised
+    // tokens move, so the second log-sum-exp follows from the first:
+    //   sum_v exp(y'_v) = (S - sum_U exp(x_v - m)) / S + sum_U exp(y'_v),  U = distinct ids.
+    // Both terms are O(1) or smaller and the total is >= ~0.5, so the subtraction
+    // costs no accuracy that matters at fp32.
+    __shared__ int s_pen[PEN_SLOTS];
+    __shared__ float s_pen_red[2][MLS_WAVES];
+    const bool pen_on = a.penalty > 0.f;
+    float lse2 = 0.f;
+    auto penalised = [&](float y) { return y < 0.f ? y * a.penalty : y / a.penalty; };
+    auto in_pen_set = [&](int tokv) {
+        uint32_t h = ((uint32_t)tokv * 0x9E3779B1u) >> (32 - PEN_SLOT_BITS);
+        for (;;) {
+            const int cur = s_pen[h];
+            if (cur == tokv) return true;
+            if (cur < 0) return false;
+            h = (h + 1) & (PEN_SLOTS - 1);
+        }
+    };
+    if (pen_on) {
+        for (int i = tid; i < PEN_SLOTS; i += MLS_THREADS) s_pen[i] = -1;
+        __syncthreads();
+        const int64_t* __restrict__ ids_row = a.ids + (int64_t)r * a.ids_stride;
+        float sub = 0.f, add = 0.f;
+        for (int t = a.pen_from + tid; t < a.T; t += MLS_THREADS) {
+            const int64_t tk = ids_row[t];
+            if (tk < 0 || tk >= (int64_t)a.V) continue;
+            const int tokv = (int)tk;
+            uint32_t h = ((uint32_t)tokv * 0x9E3779B1u) >> (32 - PEN_SLOT_BITS);
+            bool first = false;
+            for (;;) {
+                const int old = atomicCAS(&s_pen[h], -1, tokv);
+                if (old == -1) { first = true; break; }
+                if (old == tokv) break;
+                h = (h + 1) & (PEN_SLOTS - 1);
+            }
+            if (first) {
+                const float xm = E::to_float(row[tokv]) - tot.m;
+                sub += fast_exp2(xm * kLog2e);
+                add += fast_exp2(penalised(xm - log_s) * kLog2e);
+            }
+        }
+        sub = wave_sum(sub);
+        add = wave_sum(add);
+        if ((tid & (GRX_WAVE - 1)) == 0) {
+            s_pen_red[0][tid / GRX_WAVE] = sub;
+            s_pen_red[1][tid / GRX_WAVE] = add;
+        }
+        __syncthreads();  // also publishes the finished token set
+        sub = 0.f;
+        add = 0.f;
+#pragma unroll
+        for (int w = 0; w < MLS_WAVES; ++w) {
+            sub += s_pen_red[0][w];
+            add += s_pen_red[1][w];
+        }
+        lse2 = logf(fmaxf(tot.s - sub, 0.f) / tot.s + add);
+    }
+    // log-prob of allowed token `tokv` whose logit minus the row maximum is `xm`
+    auto final_logp = [&](int tokv, float xm) {
+        float y = xm - log_s;
+        if (pen_on) {
+            if (in_pen_set(tokv)) y = penalised(y);
+            y -= lse2;
+        }
+        return y;
+    };
+
     // Emit the allowed tokens.
     if (OUT == OUT_COMPACT) {
         // Whole 128-byte lines only: header + candidates + zero padding up to the next 16 entries.
@@ -414,10 +492,10 @@ __global__ __launch_bounds__(MLS_THREADS) void masked_lsm_kernel(MlsArgs a) {
                 grx_cand v = {0, 0};
                 if (e == 0) {
                     v.x = c_n;
-                    v.y = __float_as_int(tot.m + log_s);
+                    v.y = __float_as_int(tot.m + log_s + lse2);
                 } else if (e - 1 < c_n) {
                     v.x = e_tok[k];
-                    v.y = __float_as_int((e_val[k] - tot.m) - log_s);
+                    v.y = __float_as_int(final_logp(e_tok[k], e_val[k] - tot.m));
                 }
                 cand_store(crow + e, v);
             }
@@ -426,7 +504,7 @@ __global__ __launch_bounds__(MLS_THREADS) void masked_lsm_kernel(MlsArgs a) {
             grx_cand v = {0, 0};
             if (e - 1 < c_n) {
                 v.x = a.tok[c_off + e - 1];  // an EOS-only row has c_n == 1 and never gets here
-                v.y = __float_as_int((E::to_float(row[v.x]) - tot.m) - log_s);
+                v.y = __float_as_int(final_logp(v.x, E::to_float(row[v.x]) - tot.m));
             }
             cand_store(crow + e, v);
         }
@@ -438,11 +516,11 @@ __global__ __launch_bounds__(MLS_THREADS) void masked_lsm_kernel(MlsArgs a) {
 #pragma unroll
         for (int k = 0; k < MLS_EARLY; ++k) {
             const int i = tid + k * MLS_THREADS;
-            if (i < c_n) put(e_tok[k], (e_val[k] - tot.m) - log_s);
+            if (i < c_n) put(e_tok[k], final_logp(e_tok[k], e_val[k] - tot.m));
         }
         for (int i = tid + MLS_EARLY * MLS_THREADS; i < c_n; i += MLS_THREADS) {
             const int tok = a.tok[c_off + i];  // an EOS-only row has c_n == 1 and never gets here
-            put(tok, (E::to_float(row[tok]) - tot.m) - log_s);
+            put(tok, final_logp(tok, E::to_float(row[tok]) - tot.m));
         }
     }
 #ifdef MLS_STAMP
@@ -586,6 +664,18 @@ static int run_step(const char* who, const grx_trie* trie, grx_state* state, con
     a.plan = plan;
     a.st = state ? state->dev : nullptr;
     a.reset_aware = (con->mode == GRX_MODE_COUNT && con->n_prefix >= 0) ? 1 : 0;
+    a.penalty = 0.f;
+    if (con->repetition_penalty != 0.f && con->repetition_penalty != 1.f) {
+        GRX_REQUIRE(con->repetition_penalty > 0.f, GRX_E_INVALID, "%s: repetition_penalty must be positive", who);
+        GRX_REQUIRE(con->penalty_skip >= 0, GRX_E_INVALID, "%s: penalty_skip must be >= 0", who);
+        GRX_REQUIRE(rows->T - con->penalty_skip <= GRX_MAX_PENALTY_TOKENS, GRX_E_UNSUPPORTED,
+                    "%s: repetition penalty over more than %d tokens per row", who, GRX_MAX_PENALTY_TOKENS);
+        a.penalty = con->repetition_penalty;
+        a.pen_from = con->penalty_skip;
+        a.ids = rows->input_ids;
+        a.ids_stride = rows->ids_stride;
+        a.T = rows->T;
+    }
     a.R = rows->R;
     a.scores = rows->scores;
     a.scores_stride = rows->scores_stride;

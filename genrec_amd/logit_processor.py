@@ -105,6 +105,8 @@ class _TrieConstrainedBase(LogitsProcessor):
         eos_token_id: Optional[int] = None,
         *,
         sync_errors: Optional[bool] = None,
+        repetition_penalty: float = 1.0,
+        prompt_ignore_length: int = 0,
     ):
         self._prefix_allowed_tokens_fn = prefix_allowed_tokens_fn
         self._num_beams = num_beams
@@ -112,6 +114,14 @@ class _TrieConstrainedBase(LogitsProcessor):
         self.eos_token_id = eos_token_id
         self.prefix_ids = prefix_ids
         self.sync_errors = _eager_errors_default() if sync_errors is None else bool(sync_errors)
+        # Extension: transformers' RepetitionPenaltyLogitsProcessor folded into the same pass.
+        # generate() runs that processor on log_softmax(logits) right before this one when
+        # repetition_penalty != 1 (evaluate.py:218 sets 1.1); callers of the fused loop, which
+        # bypasses generate(), pass the value here instead.
+        if not repetition_penalty > 0:
+            raise ValueError(f"`penalty` has to be a strictly positive float, but is {repetition_penalty}")
+        self.repetition_penalty = float(repetition_penalty)
+        self.prompt_ignore_length = int(prompt_ignore_length or 0)
         self._trie: Optional[FlatTrie] = None
         self._states: dict[int, _DeviceState] = {}
         self._workspaces: dict[int, torch.Tensor] = {}
@@ -161,6 +171,8 @@ class _TrieConstrainedBase(LogitsProcessor):
             for i, t in enumerate(ids):
                 con.prefix_ids[i] = t
         con.eos_token_id = -1 if self.eos_token_id is None else int(self.eos_token_id)
+        con.repetition_penalty = self.repetition_penalty
+        con.penalty_skip = self.prompt_ignore_length
         return con
 
     def _rows(self, input_ids: torch.Tensor, scores: torch.Tensor) -> tuple[_lib.GrxRows, torch.Tensor, torch.Tensor]:
@@ -335,9 +347,12 @@ class ConstrainedLogitsProcessor(_TrieConstrainedBase):
         *,
         initial_count: int = 0,
         sync_errors: Optional[bool] = None,
+        repetition_penalty: float = 1.0,
+        prompt_ignore_length: int = 0,
     ):
         super().__init__(
-            prefix_allowed_tokens_fn, num_beams, prefix_index, prefix_ids, eos_token_id, sync_errors=sync_errors
+            prefix_allowed_tokens_fn, num_beams, prefix_index, prefix_ids, eos_token_id, sync_errors=sync_errors,
+            repetition_penalty=repetition_penalty, prompt_ignore_length=prompt_ignore_length,
         )
         self.initial_count = int(initial_count)
         self._count_host = self.initial_count  # value to push to a device on first use / after a set

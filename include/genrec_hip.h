@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define GRX_ABI_VERSION 1
+#define GRX_ABI_VERSION 2
 
 #if defined(GRX_BUILDING)
 #define GRX_API __attribute__((visibility("default")))
@@ -120,7 +120,17 @@ typedef struct grx_constraint {
     int32_t n_prefix;         /* -1: prefix_ids is None; else length (<= GRX_MAX_PREFIX) */
     int32_t eos_token_id;     /* -1: None                                           */
     int64_t prefix_ids[GRX_MAX_PREFIX];
+    /* Optional fused pre-processor: transformers' RepetitionPenaltyLogitsProcessor
+     * (generation/logits_process.py, the 2-D path of __call__) applied to
+     * log_softmax(scores) before the masked log-softmax, which is where generate()
+     * runs it ahead of the reference's processor when repetition_penalty != 1
+     * (evaluate.py:218,363-371).  1.0 (or 0) switches it off.  Tokens of
+     * input_ids[:, penalty_skip:] are penalised; rows may hold at most
+     * GRX_MAX_PENALTY_TOKENS tokens then. */
+    float repetition_penalty;
+    int32_t penalty_skip;     /* prompt_ignore_length of the HF processor; 0 = none  */
 } grx_constraint;
+#define GRX_MAX_PENALTY_TOKENS 1536
 
 /* Bytes of device scratch the two calls below need for R rows (required when
  * R > 0).  It holds the per-row plans a small kernel writes ahead of the

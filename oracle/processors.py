@@ -146,6 +146,19 @@ def masked_log_softmax(scores: torch.Tensor, allowed: list[list[int]]) -> torch.
     return logp + mask
 
 
+def ref_repetition_penalty(input_ids: torch.Tensor, scores: torch.Tensor, penalty: float,
+                           prompt_ignore_length: int = 0) -> torch.Tensor:
+    """transformers' RepetitionPenaltyLogitsProcessor, 2-D path (transformers 5.15.0,
+    generation/logits_process.py, ``__call__``): gather the scores of the row's tokens, multiply the
+    negative ones by the penalty and divide the others, scatter back.  generate() applies it to
+    log_softmax(logits) ahead of the custom processors (generation/utils.py:3388-3389)."""
+    if prompt_ignore_length:
+        input_ids = input_ids[:, prompt_ignore_length:]
+    score = torch.gather(scores, 1, input_ids)
+    score = torch.where(score < 0, score * penalty, score / penalty)
+    return scores.scatter(1, input_ids, score)
+
+
 # ------------------------------------------------------------- processors ---
 class RefConstrainedLogitsProcessor:
     """logit_processor.py:8-49 (+ ``initial_count``: analyze_rl_beam_hint.py:553-560)."""

@@ -112,6 +112,64 @@ def test_beam_step_matches_oracle_stepwise(case):
         assert st.has_unfinished() == ref.has_unfinished()
 
 
+def test_fused_loop_with_repetition_penalty_matches_the_oracle_loop():
+    """evaluate.py decodes with repetition_penalty=1.1 (evaluate.py:218): generate() then runs
+    RepetitionPenaltyLogitsProcessor ahead of the trie processor at every step.  The fused loop with
+    repetition_penalty= on the processor returns the same rankings as the oracle loop with that chain."""
+    from oracle.beam import ref_constrained_beam_search
+    from oracle.processors import DictTrie, RefConstrainedLogitsProcessor, ref_repetition_penalty
+
+    from genrec_amd.beam import constrained_beam_search
+    from genrec_amd.logit_processor import ConstrainedLogitsProcessor
+    from genrec_amd.trie import FlatTrie, create_prefix_allowed_tokens_fn
+
+    dev = _dev()
+    data, meta = load_npz("beams.npz")
+    case = "count_k16_lp0"
+    info = meta["cases"][case]
+    K, prefix, eos, pad = info["K"], meta["prefix"], meta["eos"], meta["pad"]
+    seqs = data["trie_sequences"].tolist()
+    trie = FlatTrie(seqs)
+    fn = create_prefix_allowed_tokens_fn(trie, prefix)
+    prompts = torch.from_numpy(data[f"{case}.prompts"])
+    # history: the prompt repeats tokens that the trie can propose
+    sid = sorted({t for s in seqs for t in s[len(prefix):-1]})
+    g = torch.Generator().manual_seed(5)
+    prompts[:, :6] = torch.tensor(sid)[torch.randint(0, len(sid), (prompts.shape[0], 6), generator=g)]
+    logits = [torch.from_numpy(data[f"{case}.logits.{t}"]) for t in range(info["steps"])]
+    penalty = 1.1
+
+    class Chain:
+        def __init__(self):
+            self.inner = RefConstrainedLogitsProcessor(DictTrie(seqs).get, K, 3, prefix, eos)
+
+        def reset(self):
+            self.inner.reset()
+
+        def __call__(self, ids, lp):
+            return self.inner(ids, ref_repetition_penalty(ids, lp, penalty))
+
+    ref_state, _ = ref_constrained_beam_search(lambda step, flat: logits[step], Chain(), prompts, K,
+                                               info["max_new_tokens"], eos, pad, info["length_penalty"])
+    want_seqs, want_scores, want_bidx = ref_state.finalize()
+    proc = ConstrainedLogitsProcessor(fn, K, 3, prefix, eos, sync_errors=True, repetition_penalty=penalty)
+    dev_logits = [x.to(dev) for x in logits]
+    _, got_seqs, got_scores, got_bidx = constrained_beam_search(
+        lambda step, flat, parent: dev_logits[step], proc, prompts.to(dev), K, info["max_new_tokens"], eos, pad,
+        info["length_penalty"])
+    live = want_scores > LIVE
+    assert torch.equal(live, got_scores.cpu() > LIVE)
+    assert torch.equal(got_seqs.cpu()[live], want_seqs[live])
+    assert torch.equal(got_bidx.cpu()[live].long(), want_bidx[live].long())
+    assert float((got_scores.cpu()[live] - want_scores[live]).abs().max()) <= SCORE_TOL
+    # the penalty changes the outcome (otherwise this test would not see it)
+    plain = ConstrainedLogitsProcessor(fn, K, 3, prefix, eos, sync_errors=True)
+    _, _, plain_scores, _ = constrained_beam_search(
+        lambda step, flat, parent: dev_logits[step], plain, prompts.to(dev), K, info["max_new_tokens"], eos, pad,
+        info["length_penalty"])
+    assert not torch.equal(plain_scores.cpu()[live], got_scores.cpu()[live])
+
+
 def test_beam_step_large_random_against_oracle():
     """Synthetic candidates at rollout scale (K=16 and K=50, fan-out up to 242): exact top-2K order."""
     from oracle.beam import RefBeamSearch

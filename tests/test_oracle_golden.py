@@ -225,3 +225,35 @@ def test_cascade_oracle_matches_reference_golden():
         assert [{"groups": c["groups"], "depths": c["depths"]} for c in out["calls"]] == want["calls"]
         multi += case["others"] is not None
     assert multi >= 8  # scenarios in which other ranks keep the cascade running
+
+
+def test_penalty_chain_oracle_bit_exact_with_reference(tmp_path):
+    """log_softmax -> repetition penalty -> processor, restated in oracle/, equals the values recorded
+    from transformers' RepetitionPenaltyLogitsProcessor feeding the reference's processors."""
+    from genrec_amd.synth import ASSISTANT_PREFIX, SidTokenizer
+    from genrec_amd.trie import build_trie_from_index
+
+    data, meta = load_npz("penalty.npz")
+    path = write_index_file("Instruments", tmp_path)
+    tok = SidTokenizer.from_index(path)
+    trie, suffix, pidx = build_trie_from_index(path, tok, prefix=ASSISTANT_PREFIX)
+    o_trie = oproc.DictTrie(sorted(trie))
+    K, V, eos = meta["K"], meta["V"], meta["eos"]
+    for ci, case in enumerate(meta["cases"]):
+        ids = torch.from_numpy(data[f"{ci}.ids"])
+        logits = torch.randn(ids.shape[0], V, generator=torch.Generator().manual_seed(case["seed"])) * meta["scale"]
+        if case["peaked"]:
+            logits[torch.arange(ids.shape[0]), ids[:, 7]] += 40.0
+        lp = torch.nn.functional.log_softmax(logits, dim=-1)
+        pen = oproc.ref_repetition_penalty(ids, lp, case["penalty"], case["skip"])
+        if case["processor"] == "count":
+            proc = oproc.RefConstrainedLogitsProcessor(o_trie.get, K, pidx, None, eos)
+            proc.count = case["step"]
+        else:
+            proc = oproc.RefFixedHintConstrainedLogitsProcessor(o_trie.get, K, pidx, suffix, eos)
+        out = proc(ids, pen)
+        for r in range(ids.shape[0]):
+            n = int(data[f"{ci}.count"][r])
+            cols = torch.nonzero(torch.isfinite(out[r])).flatten()
+            assert cols.tolist() == data[f"{ci}.tok"][r, :n].tolist()
+            assert np.array_equal(out[r, cols].numpy(), data[f"{ci}.val"][r, :n])
