@@ -14,7 +14,10 @@ Host-side mirror of ``llamafactory.extras.trie.Trie``
 from __future__ import annotations
 
 import ctypes as C
+import hashlib
 import json
+import os
+import struct
 from collections import deque
 from typing import Callable, Iterable, Iterator, Optional, Sequence
 
@@ -103,6 +106,45 @@ class FlatTrie:
                 if nodes > max_nodes:
                     raise ValueError("prefix_allowed_tokens_fn enumerates more than max_nodes nodes")
         return cls.from_nested_dict(nested)
+
+    # -- binary form ------------------------------------------------------------
+    # Layout (little endian): 8-byte magic "GRXTRIE1", int32 n_nodes, int32 n_edges, int64 len,
+    # 32-byte key (SHA-256 of whatever the trie was built from, zeros when unknown),
+    # child_off int32[n_nodes + 1], child_tok int32[n_edges].
+    MAGIC = b"GRXTRIE1"
+
+    def save(self, path: str, key: bytes = b"") -> None:
+        key = (key + b"\0" * 32)[:32]
+        tmp = f"{path}.tmp{os.getpid()}"
+        with open(tmp, "wb") as f:
+            f.write(self.MAGIC)
+            f.write(struct.pack("<iiq", self.n_nodes, self.n_edges, self.len))
+            f.write(key)
+            f.write(np.ascontiguousarray(self.child_off, dtype="<i4").tobytes())
+            f.write(np.ascontiguousarray(self.child_tok, dtype="<i4").tobytes())
+        os.replace(tmp, path)  # readers never see a half-written cache
+
+    @classmethod
+    def load(cls, path: str, key: Optional[bytes] = None) -> "FlatTrie":
+        """Read a file written by ``save``; with ``key`` given, a different stored key raises KeyError."""
+        with open(path, "rb") as f:
+            head = f.read(8 + 16 + 32)
+            if len(head) != 56 or head[:8] != cls.MAGIC:
+                raise ValueError(f"{path} is not a trie cache")
+            n_nodes, n_edges, length = struct.unpack("<iiq", head[8:24])
+            if key is not None and head[24:56] != (key + b"\0" * 32)[:32]:
+                raise KeyError(f"{path} was built from different inputs")
+            if n_nodes < 1 or n_edges != n_nodes - 1:
+                raise ValueError(f"{path}: inconsistent header")
+            off = np.frombuffer(f.read(4 * (n_nodes + 1)), dtype="<i4")
+            tok = np.frombuffer(f.read(4 * n_edges), dtype="<i4")
+        if off.shape[0] != n_nodes + 1 or tok.shape[0] != n_edges or off[0] != 0 or off[-1] != n_edges:
+            raise ValueError(f"{path}: truncated or corrupt")
+        out = cls()
+        out.child_off = off.astype(np.int32)
+        out.child_tok = tok.astype(np.int32)
+        out.len = int(length)
+        return out
 
     # -- queries (host) ---------------------------------------------------------
     @property
@@ -252,22 +294,56 @@ def index_item_strings(index_path: str, sid_levels: int = -1) -> set[str]:
     return items
 
 
-def build_trie_from_index(index_path: str, tokenizer, prefix: Optional[str] = None, sid_levels: int = -1):
+def _trie_cache_key(index_path: str, tokenizer, prefix: str, prefix_ids: list[int], sid_levels: int) -> bytes:
+    """Everything the token sequences depend on: the index bytes, the level cut, the prefix and
+    its ids, EOS, and the ids the tokenizer gives to every SID token of the index."""
+    h = hashlib.sha256()
+    with open(index_path, "rb") as f:
+        h.update(f.read())
+    h.update(repr((sid_levels, prefix, prefix_ids, tokenizer.eos_token_id)).encode())
+    with open(index_path, encoding="utf-8") as f:
+        toks = sorted({t for raw in json.load(f).values() for t in normalize_sid_tokens(raw)})
+    ids = tokenizer("".join(toks), add_special_tokens=False).input_ids if toks else []
+    h.update(np.asarray(ids, dtype="<i8").tobytes())
+    return h.digest()
+
+
+def build_trie_from_index(index_path: str, tokenizer, prefix: Optional[str] = None, sid_levels: int = -1,
+                          cache: bool = False):
     """index.json -> (trie, prompt_suffix_ids, prefix_index) (reference: evaluate.py:63-95).
 
     Every trie path is ``prefix_ids + sid_ids + [eos]``; ``len(trie)`` is the
     number of distinct items.
+
+    ``cache=True`` (extension) keeps the flat trie in ``<index_path>.<key>.grxtrie`` next to the index
+    and reads it back when index, tokenizer ids, prefix and level cut are unchanged: every rank
+    and every run after the first skips the JSON parse and the per-item tokenizer calls.
     """
-    items = index_item_strings(index_path, sid_levels)
     if prefix is None:
         prefix = get_assistant_prefix_from_tokenizer(tokenizer)
     prefix_ids = list(tokenizer(prefix, add_special_tokens=False).input_ids)
+    cache_path = key = None
+    if cache:
+        key = _trie_cache_key(index_path, tokenizer, prefix, prefix_ids, sid_levels)
+        cache_path = f"{index_path}.{key.hex()[:16]}.grxtrie"
+        if os.path.exists(cache_path):
+            try:
+                return FlatTrie.load(cache_path, key), prefix_ids, len(prefix_ids)
+            except (KeyError, ValueError, OSError):
+                pass  # stale or damaged: rebuild below
+    items = index_item_strings(index_path, sid_levels)
     eos_id = tokenizer.eos_token_id
     sequences = []
     for item in items:
         full = tokenizer(prefix + item, add_special_tokens=False).input_ids
         sequences.append(prefix_ids + list(full[len(prefix_ids) :]) + [eos_id])
-    return FlatTrie(sequences), prefix_ids, len(prefix_ids)
+    trie = FlatTrie(sequences)
+    if cache_path is not None:
+        try:
+            trie.save(cache_path, key)
+        except OSError:
+            pass  # read-only data directory: the cache is only an optimisation
+    return trie, prefix_ids, len(prefix_ids)
 
 
 def create_prefix_allowed_tokens_fn(trie, prompt_suffix_ids: list[int]) -> Callable[[list[int]], list[int]]:

@@ -214,3 +214,51 @@ def test_dynamic_hint_cascade_makes_the_reference_decisions(monkeypatch):
         codes = tok.code_table()
         rows = [[int(codes[t]) for t in row if codes[t] >= 0] for row in got.completion_ids.tolist()]
         assert rows == want["selected_completions"]
+
+
+def test_result_json_and_metrics_straight_from_beam_ids(tmp_path):
+    """result.json written from beam token ids has the reference's layout (evaluate.py:382-389); the
+    metrics computed from the ids equal the metrics the text path computes from that file and the
+    oracle's restatement of evaluate.compute_metrics."""
+    import json
+
+    from oracle.scoring import ref_compute_metrics
+
+    from genrec_amd.metrics import compute_metrics
+    from genrec_amd.results import token_text_table, write_result_json
+    from genrec_amd.synth import SidTokenizer
+
+    dev = _dev()
+    tok = SidTokenizer(f"<{l}_{c}>" for l in "abcd" for c in range(8))
+    table = token_text_table(tok, tok.vocab_size_padded)
+    rng = np.random.default_rng(3)
+    n, K, L = 64, 20, 4
+    items = rng.integers(0, 8, size=(n, K, L))
+    items[:, 1:, 3] = (items[:, :1, 3] + np.arange(1, K)[None, :]) % 8 + 8 * 0  # keep beams of a sample distinct-ish
+    target = items[np.arange(n), rng.integers(0, K, size=n)].copy()
+    target[::5] = 7  # some targets nobody predicted (unless by accident)
+
+    def ids_of(codes):
+        return [tok.encode(f"<{'abcd'[l]}_{int(c)}>")[0] for l, c in enumerate(codes)]
+
+    beams = np.array([[ids_of(b) + [tok.eos_token_id] for b in sample] for sample in items])
+    beams[:, :, -1] = np.where(rng.random((n, K)) < 0.5, tok.eos_token_id, tok.pad_token_id)
+    tgt = np.array([ids_of(t) for t in target])
+    test_data = [{"instruction": f"q{i}", "output": "".join(f"<{'abcd'[l]}_{int(c)}>" for l, c in enumerate(t))}
+                 for i, t in enumerate(target)]
+    path = str(tmp_path / "run" / "result.json")
+    metrics = write_result_json(test_data, torch.from_numpy(beams).to(dev), table, path,
+                                target_ids=torch.from_numpy(tgt).to(dev))
+    with open(path, encoding="utf-8") as f:
+        text = f.read()
+    records = json.loads(text)
+    assert text == json.dumps(records, indent=4, ensure_ascii=False)
+    assert [r["predict"] for r in records] == [[tok.decode(b) for b in sample] for sample in beams]
+    assert all(r["output"] == d["output"] and r["instruction"] == d["instruction"] for r, d in zip(records, test_data))
+    want = ref_compute_metrics(records)
+    assert metrics.keys() == want.keys()
+    assert all(abs(metrics[k] - want[k]) <= 1e-12 for k in want)
+    from_text = compute_metrics(records)
+    assert all(abs(from_text[k] - want[k]) <= 1e-12 for k in want)
+    saved = json.load(open(tmp_path / "run" / "metrics.json"))
+    assert saved == {k: round(v, 4) for k, v in want.items()}

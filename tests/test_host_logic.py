@@ -205,3 +205,50 @@ def test_cascade_hinted_prompts_are_left_padded_prompt_plus_hint():
     rows = hinted_prompts(prompts, gt, torch.tensor([3, 1], dtype=torch.int32), 3 + 3, 0)
     assert rows.tolist() == [[5, 6, 7, 101, 102, 103], [0, 0, 8, 9, 10, 201]]
     assert hinted_prompts(prompts, gt, torch.tensor([0, 0], dtype=torch.int32), 3, 0).tolist() == prompts.tolist()
+
+
+def test_trie_cache_round_trip_and_staleness(tmp_path):
+    import json as _json
+
+    from genrec_amd.synth import ASSISTANT_PREFIX, SidTokenizer, synthetic_index, write_index
+    from genrec_amd.trie import FlatTrie, build_trie_from_index
+
+    path = write_index(str(tmp_path / "a.index.json"), synthetic_index(300, 4, 16, seed=1))
+    tok = SidTokenizer.from_index(path)
+    built, suffix, pidx = build_trie_from_index(path, tok, prefix=ASSISTANT_PREFIX, cache=True)
+    files = [f for f in os.listdir(tmp_path) if f.endswith(".grxtrie")]
+    assert len(files) == 1
+    cached, suffix2, pidx2 = build_trie_from_index(path, tok, prefix=ASSISTANT_PREFIX, cache=True)
+    assert (suffix2, pidx2, len(cached)) == (suffix, pidx, len(built))
+    assert np.array_equal(cached.child_off, built.child_off) and np.array_equal(cached.child_tok, built.child_tok)
+    assert sorted(cached) == sorted(built)
+    # a different level cut, a changed index, or a changed tokenizer never reuses the file
+    t3, _, _ = build_trie_from_index(path, tok, prefix=ASSISTANT_PREFIX, sid_levels=3, cache=True)
+    assert t3.n_nodes != built.n_nodes and len([f for f in os.listdir(tmp_path) if f.endswith(".grxtrie")]) == 2
+    index = _json.load(open(path))
+    index["0"] = ["<a_15>", "<b_15>", "<c_15>", "<d_15>"]
+    write_index(path, index)
+    rebuilt, _, _ = build_trie_from_index(path, tok, prefix=ASSISTANT_PREFIX, cache=True)
+    fresh, _, _ = build_trie_from_index(path, tok, prefix=ASSISTANT_PREFIX)
+    assert np.array_equal(rebuilt.child_tok, fresh.child_tok) and np.array_equal(rebuilt.child_off, fresh.child_off)
+    # a damaged cache file is rebuilt, and load() refuses foreign files
+    victim = str(tmp_path / [f for f in os.listdir(tmp_path) if f.endswith(".grxtrie")][0])
+    with open(victim, "r+b") as f:
+        f.truncate(80)
+    with pytest.raises(ValueError):
+        FlatTrie.load(victim)
+    with pytest.raises(KeyError):
+        good = [str(tmp_path / f) for f in os.listdir(tmp_path) if f.endswith(".grxtrie") and str(tmp_path / f) != victim][0]
+        FlatTrie.load(good, key=b"x" * 32)
+
+
+def test_decode_beams_reproduces_batch_decode():
+    from genrec_amd.results import decode_beams, token_text_table
+    from genrec_amd.synth import SidTokenizer
+
+    tok = SidTokenizer(f"<{l}_{c}>" for l in "abcd" for c in range(5))
+    table = token_text_table(tok, len(tok) + 7)
+    ids = np.array([[[tok.encode("<a_1>")[0], tok.encode("<b_2>")[0], tok.eos_token_id, tok.pad_token_id],
+                     [tok.encode("<a_0>")[0], tok.encode("<b_4>")[0], tok.encode("<c_3>")[0], tok.eos_token_id]]])
+    assert decode_beams(ids, table) == [["<a_1><b_2>", "<a_0><b_4><c_3>"]]
+    assert decode_beams(ids, table)[0] == [tok.decode(r) for r in ids[0]]
