@@ -272,6 +272,8 @@ def main() -> None:
 
     from genrec_amd import _lib
 
+    if os.environ.get("GENREC_BENCH_LIB"):  # kernel tuning: time a variant build instead of the shipped library
+        _lib.LIB_PATH = os.path.abspath(os.environ["GENREC_BENCH_LIB"])
     wl = build_workload(args, device)
     roll = Rollout(args, wl, device)
 
@@ -351,7 +353,7 @@ def main() -> None:
         }
         if world == 1 and not args.no_processor_surface:
             out["processor_surface"] = time_processor_surface(args, wl, device)
-        if not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = time_cpu_baseline(args, wl)
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -95,7 +95,7 @@ struct RowStream {
 };
 
 #ifndef MLS_NTST
-#define MLS_NTST 0        // 1: non-temporal stores for the candidate rows
+#define MLS_NTST 1        // 1: non-temporal stores for the candidate rows (measured: 397 -> 386 us at 162 candidates per row, 378 -> 373 at 43)
 #endif
 #ifndef MLS_NTFILL
 #define MLS_NTFILL 0      // 1: non-temporal stores for the -inf fill of the dense output
