@@ -22,6 +22,7 @@
 struct BeamDerived {
     float fin_div;    // (cur_len + 1 - prompt_len) ** length_penalty
     float heur_div;   // best_hypothetical_length ** length_penalty
+    int reg_keys;     // every candidate slot is covered by the opening batch of loads: keys stay in registers
     int lds_keys;     // capacity of the dynamic LDS key buffer (0: rescan global memory)
     int tails_in_lds; // the re-ordered parts of the sequence / parent rows fit the LDS tail buffers
 };
@@ -153,7 +154,58 @@ __global__ __launch_bounds__(BS_THREADS) void beam_step_kernel(grx_beam_step_arg
     // (the n_keep-th largest of the per-thread maxima, which at least n_keep keys
     // reach) leaves a few dozen survivors; they are ranked against each other.
     bool selected = false;
-    if (staged) {
+    if (d.reg_keys) {
+        // K <= BS_PREFETCH beams of at most BS_THREADS candidates, n_keep <= 64: thread t holds column t
+        // of every beam.  64 partition maxima (lane-wise over the four waves) give the threshold.
+        unsigned long long rk[BS_PREFETCH];
+        unsigned long long tmax = 0;
+#pragma unroll
+        for (int u = 0; u < BS_PREFETCH; ++u) {
+            rk[u] = (u < K && tid < cmax) ? key_at(u, tid, __int_as_float(pre[u].y), pre[u].x) : 0ull;
+            tmax = rk[u] > tmax ? rk[u] : tmax;
+        }
+        s_tmax[tid] = tmax;
+        STAMP(3);
+        __syncthreads();
+        if (wave == 0) {
+            unsigned long long pm = s_tmax[lane];
+#pragma unroll
+            for (int w = 1; w < BS_WAVES; ++w) pm = s_tmax[lane + w * GRX_WAVE] > pm ? s_tmax[lane + w * GRX_WAVE] : pm;
+            int rank = 0;  // keys are unique, so the partition maxima are distinct (or 0)
+            const int pm_lo = (int)(unsigned)(pm & 0xFFFFFFFFull), pm_hi = (int)(unsigned)(pm >> 32);
+#pragma unroll
+            for (int j = 0; j < GRX_WAVE; ++j) {  // lane j's value as a scalar: no LDS traffic
+                const unsigned lo = (unsigned)__builtin_amdgcn_readlane(pm_lo, j);
+                const unsigned hi = (unsigned)__builtin_amdgcn_readlane(pm_hi, j);
+                rank += (((unsigned long long)hi << 32) | lo) > pm ? 1 : 0;
+            }
+            if (pm != 0 && rank == n_keep - 1) s_thresh = pm;  // stays 0 when fewer than n_keep partitions hold a key
+        }
+        STAMP(5);
+        __syncthreads();
+        const unsigned long long thresh = s_thresh;
+#pragma unroll
+        for (int u = 0; u < BS_PREFETCH; ++u) {
+            if (rk[u] != 0 && rk[u] >= thresh) {
+                const int at = atomicAdd(&s_nsurv, 1);
+                if (at < BS_SURV_CAP) s_surv[at] = rk[u];
+            }
+        }
+        STAMP(6);
+        __syncthreads();
+        const int M = s_nsurv;
+        if (M <= BS_SURV_CAP) {
+            for (int i = tid; i < M; i += BS_THREADS) {
+                const unsigned long long kv = s_surv[i];
+                int rank = 0;
+#pragma unroll 8
+                for (int j = 0; j < M; ++j) rank += s_surv[j] > kv ? 1 : 0;
+                if (rank < n_keep) emit(rank, kv);
+            }
+            for (int j = M + tid; j < n_keep; j += BS_THREADS) emit(j, 0);
+            selected = true;
+        }
+    } else if (staged) {
         // slot layout in LDS: beam-major, s_keys[k * cmax + i]
 #pragma unroll
         for (int u = 0; u < BS_PREFETCH; ++u) {
@@ -263,20 +315,37 @@ __global__ __launch_bounds__(BS_THREADS) void beam_step_kernel(grx_beam_step_arg
     __syncthreads();
 
     // ---- running top-K (of n_keep) and finished top-K (of K + n_keep) by rank counting
-    for (int j = tid; j < n_keep; j += BS_THREADS) {
-        const float v = s_rs[j];
-        int rank = 0;
-#pragma unroll 8
-        for (int i = 0; i < n_keep; ++i) rank += ranks_before(s_rs[i], i, v, j) ? 1 : 0;
-        if (rank < K) s_run_idx[rank] = j;
-    }
     const int n_merged = K + n_keep;
-    for (int j = tid; j < n_merged; j += BS_THREADS) {
-        const float v = s_merged[j];
-        int rank = 0;
+    if (n_merged <= GRX_WAVE) {
+        // both lists fit one wave each: wave 0 ranks the running scores, wave 1 the merged finished
+        // scores, lane j against every lane's value broadcast as a scalar
+        if (wave < 2) {
+            const int n = wave == 0 ? n_keep : n_merged;
+            const float v = lane < n ? (wave == 0 ? s_rs[lane] : s_merged[lane]) : -INFINITY;
+            const int vi = __float_as_int(v);
+            int rank = 0;
+#pragma unroll
+            for (int i = 0; i < GRX_WAVE; ++i) {  // constant lane indices: scalar broadcasts, no LDS traffic
+                const float o = __int_as_float(__builtin_amdgcn_readlane(vi, i));
+                rank += (i < n && ranks_before(o, i, v, lane)) ? 1 : 0;
+            }
+            if (lane < n && rank < K) (wave == 0 ? s_run_idx : s_fin_idx)[rank] = lane;
+        }
+    } else {
+        for (int j = tid; j < n_keep; j += BS_THREADS) {
+            const float v = s_rs[j];
+            int rank = 0;
 #pragma unroll 8
-        for (int i = 0; i < n_merged; ++i) rank += ranks_before(s_merged[i], i, v, j) ? 1 : 0;
-        if (rank < K) s_fin_idx[rank] = j;
+            for (int i = 0; i < n_keep; ++i) rank += ranks_before(s_rs[i], i, v, j) ? 1 : 0;
+            if (rank < K) s_run_idx[rank] = j;
+        }
+        for (int j = tid; j < n_merged; j += BS_THREADS) {
+            const float v = s_merged[j];
+            int rank = 0;
+#pragma unroll 8
+            for (int i = 0; i < n_merged; ++i) rank += ranks_before(s_merged[i], i, v, j) ? 1 : 0;
+            if (rank < K) s_fin_idx[rank] = j;
+        }
     }
     STAMP(10);
     __syncthreads();
@@ -371,7 +440,18 @@ __global__ __launch_bounds__(BS_THREADS) void beam_step_kernel(grx_beam_step_arg
     STAMP(13);
 
     // ---- early-stop heuristic for the next iteration
-    if (tid == 0) {
+    if (K <= GRX_WAVE) {
+        if (wave == 0) {
+            const float best_possible = s_rs[s_run_idx[0]] / d.heur_div;
+            const float mine = lane < K ? s_newfin[lane] : INFINITY;
+            float worst_all = mine;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) worst_all = fminf(worst_all, __shfl_xor(worst_all, o, GRX_WAVE));
+            const float worst = (lane < K && s_newdone[lane]) ? worst_all : -1.0e9f;
+            const bool any = __ballot(lane < K && best_possible > worst) != 0ull;
+            if (lane == 0) a.unsat[b] = (unsat_old && any) ? 1 : 0;
+        }
+    } else if (tid == 0) {
         const float best_possible = s_rs[s_run_idx[0]] / d.heur_div;
         float worst_all = s_newfin[0];
 #pragma unroll 8
@@ -420,7 +500,8 @@ extern "C" int grx_beam_step(const grx_beam_step_args* args, void* stream) {
                                                                        : (a.cur_len + 1 - a.prompt_len);
     d.heur_div = (float)pow((double)hyp, lp);
     const int64_t slots = (int64_t)a.K * a.cmax;
-    d.lds_keys = slots <= BS_LDS_KEYS_MAX ? (int)slots : 0;
+    d.reg_keys = (a.K <= BS_PREFETCH && a.cmax <= BS_THREADS && a.n_keep <= GRX_WAVE) ? 1 : 0;
+    d.lds_keys = (!d.reg_keys && slots <= BS_LDS_KEYS_MAX) ? (int)slots : 0;
     d.tails_in_lds = (a.K <= BS_TAIL_K && a.cur_len + 1 - a.copy_from <= BS_TAIL_W &&
                       a.cur_len - a.prompt_len + 1 <= BS_TAIL_W) ? 1 : 0;
     const size_t lds_bytes = (size_t)d.lds_keys * sizeof(unsigned long long);
