@@ -186,6 +186,12 @@ class _TrieConstrainedBase(LogitsProcessor):
             raise RuntimeError(
                 f"shape '[-1, {self._num_beams}, {input_ids.shape[1]}]' is invalid for input of size {input_ids.numel()}"
             )
+        if input_ids.shape[1] == 0:
+            # the reference's view(-1, num_beams, 0) cannot infer the group dimension (logit_processor.py:36)
+            raise RuntimeError(
+                f"cannot reshape tensor of 0 elements into shape [-1, {self._num_beams}, 0] because the "
+                "unspecified dimension size -1 can be any value and is ambiguous"
+            )
         if input_ids.dtype != torch.int64:
             input_ids = input_ids.to(torch.int64)
         if input_ids.shape[1] > 0 and input_ids.stride(1) != 1:

@@ -421,6 +421,70 @@ def test_fused_repetition_penalty_matches_the_transformers_chain():
         ConstrainedLogitsProcessor(fn, K, pidx, None, eos, repetition_penalty=0.0)
 
 
+def test_empty_and_degenerate_batches_follow_the_reference():
+    """No rows, rows shorter than the window, rows without tokens, one-beam groups: same results,
+    same counter movement and same exceptions as the oracle."""
+    from oracle.processors import (DictTrie, RefConstrainedLogitsProcessor,
+                                   RefFixedHintConstrainedLogitsProcessor)
+
+    from genrec_amd.fixed_hint_logit_processor import FixedHintConstrainedLogitsProcessor
+    from genrec_amd.logit_processor import ConstrainedLogitsProcessor
+    from genrec_amd.trie import FlatTrie, create_prefix_allowed_tokens_fn
+
+    data, meta, _, _ = _small_setup()
+    dev = _dev()
+    seqs = data["trie_sequences"].tolist()
+    trie = FlatTrie(seqs)
+    fn = create_prefix_allowed_tokens_fn(trie, meta["prefix"])
+    o_get = DictTrie(seqs).get
+    prefix, eos, V = meta["prefix"], meta["eos"], 2048
+
+    def pair(kind, K):
+        if kind == "count":
+            return (ConstrainedLogitsProcessor(fn, K, 3, prefix, eos, sync_errors=True),
+                    RefConstrainedLogitsProcessor(o_get, K, 3, prefix, eos))
+        return (FixedHintConstrainedLogitsProcessor(fn, K, 3, prefix, eos, sync_errors=True),
+                RefFixedHintConstrainedLogitsProcessor(o_get, K, 3, prefix, eos))
+
+    def same(got, want):
+        assert got.shape == want.shape
+        assert torch.equal(torch.isfinite(got.cpu()), torch.isfinite(want))
+        fin = torch.isfinite(want)
+        if fin.any():
+            assert float((got.cpu()[fin] - want[fin]).abs().max()) <= FP32_TOL
+
+    torch.manual_seed(1)
+    # no rows at all: nothing to emit, the shared counter still advances (logit_processor.py:48)
+    ours, ref = pair("count", 4)
+    out = ours(torch.zeros((0, 7), dtype=torch.int64, device=dev), torch.zeros((0, V), device=dev))
+    assert out.shape == (0, V)
+    ref(torch.zeros((0, 7), dtype=torch.int64), torch.zeros((0, V)))
+    assert ours.count == ref.count == 1
+    assert ours.candidates(torch.zeros((0, 7), dtype=torch.int64, device=dev), torch.zeros((0, V), device=dev)).count.numel() == 0
+    # one-beam groups, rows that are exactly the prefix / shorter than the window / empty
+    for kind in ("count", "fixed"):
+        for ids in (torch.tensor([prefix, prefix]), torch.tensor([prefix[1:]]), torch.zeros((2, 0), dtype=torch.int64)):
+            ours, ref = pair(kind, 1)
+            scores = torch.randn(ids.shape[0], V) * 3
+            try:
+                want = ref(ids, scores)
+            except (AssertionError, ValueError, RuntimeError) as e:
+                with pytest.raises(type(e)):
+                    ours(ids.to(dev), scores.to(dev))
+                continue
+            same(ours(ids.to(dev), scores.to(dev)), want)
+    # a row count that does not split into groups fails like the reference's view() does
+    ours, ref = pair("count", 4)
+    with pytest.raises(RuntimeError):
+        ref(torch.tensor([prefix] * 3), torch.zeros(3, V))
+    with pytest.raises(RuntimeError):
+        ours(torch.tensor([prefix] * 3).to(dev), torch.zeros(3, V, device=dev))
+    # the trie's largest token must be a column of the scores
+    ours, _ = pair("count", 1)
+    with pytest.raises(Exception):
+        ours(torch.tensor([prefix]).to(dev), torch.zeros(1, 8, device=dev))
+
+
 def test_strided_inputs_and_unnormalised_extremes():
     """Non-contiguous views, very peaked rows and rows containing -inf."""
     from oracle.processors import DictTrie, RefFixedHintConstrainedLogitsProcessor
