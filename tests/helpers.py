@@ -83,3 +83,14 @@ def cascade_case_tensors(case, device, prompt_len: int = 7, seed: int = 0):
         rows = [ids(c, d) + [tok.eos_token_id] + [tok.pad_token_id] * d for c in comps]
         table[(grp, d)] = torch.tensor(rows, dtype=torch.int64, device=device)
     return tok, prompts, gt, caps, table
+
+
+def ragged_beam_cases():
+    """(data, meta, trie sequences) of tests/golden/beams_ragged.npz."""
+    data, meta = load_npz("beams_ragged.npz")
+    flat, lens = data["trie_sequences_flat"].tolist(), data["trie_sequence_lengths"].tolist()
+    seqs, at = [], 0
+    for n in lens:
+        seqs.append(flat[at : at + n])
+        at += n
+    return data, meta, seqs

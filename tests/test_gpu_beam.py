@@ -170,6 +170,47 @@ def test_fused_loop_with_repetition_penalty_matches_the_oracle_loop():
     assert not torch.equal(plain_scores.cpu()[live], got_scores.cpu()[live])
 
 
+def test_fused_loop_on_a_ragged_trie_in_every_stopping_mode():
+    """generate() traces on a trie whose items have 1..4 levels, early_stopping False / True / "never",
+    length_penalty 0 / 1 / 2 / -0.5: the fused loop stops after the same number of steps and returns the
+    same sequences and beam parents (bit-exact) and scores (1e-5) on live beams."""
+    from helpers import ragged_beam_cases
+
+    from genrec_amd.beam import constrained_beam_search
+    from genrec_amd.fixed_hint_logit_processor import FixedHintConstrainedLogitsProcessor
+    from genrec_amd.trie import FlatTrie, create_prefix_allowed_tokens_fn
+
+    dev = _dev()
+    data, meta, seqs = ragged_beam_cases()
+    prefix, eos, pad = meta["prefix"], meta["eos"], meta["pad"]
+    fn = create_prefix_allowed_tokens_fn(FlatTrie(seqs), prefix)
+    prompts = torch.from_numpy(data["prompts"]).to(dev)
+    for name, info in meta["cases"].items():
+        K = info["K"]
+        proc = FixedHintConstrainedLogitsProcessor(fn, K, 3, prefix, eos, sync_errors=True)
+        logits = [torch.from_numpy(data[f"{name}.logits.{t}"]).to(dev) for t in range(info["steps"])]
+        calls = []
+
+        def logits_fn(step, flat, parent):
+            calls.append(step)
+            return logits[step]
+
+        _, got_seqs, got_scores, got_bidx = constrained_beam_search(
+            logits_fn, proc, prompts, K, info["max_new_tokens"], eos, pad, info["length_penalty"],
+            info["early_stopping"])
+        assert len(calls) == info["steps"], f"{name}: stopped after {len(calls)} steps, generate() after {info['steps']}"
+        want_scores = torch.from_numpy(data[f"{name}.sequences_scores"])
+        want_seqs = torch.from_numpy(data[f"{name}.sequences"])
+        want_bidx = torch.from_numpy(data[f"{name}.beam_indices"])
+        live = want_scores > LIVE
+        got_seqs, got_scores, got_bidx = got_seqs.cpu(), got_scores.cpu(), got_bidx.cpu()
+        assert torch.equal(live, got_scores > LIVE), name
+        w, bw = min(got_seqs.shape[1], want_seqs.shape[1]), min(got_bidx.shape[1], want_bidx.shape[1])
+        assert torch.equal(got_seqs[:, :w][live], want_seqs[:, :w][live]), name
+        assert torch.equal(got_bidx[:, :bw].long()[live], want_bidx[:, :bw].long()[live]), name
+        assert float((got_scores[live] - want_scores[live]).abs().max()) <= SCORE_TOL, name
+
+
 def test_beam_step_large_random_against_oracle():
     """Synthetic candidates at rollout scale (K=16 and K=50, fan-out up to 242): exact top-2K order."""
     from oracle.beam import RefBeamSearch

@@ -257,3 +257,33 @@ def test_penalty_chain_oracle_bit_exact_with_reference(tmp_path):
             cols = torch.nonzero(torch.isfinite(out[r])).flatten()
             assert cols.tolist() == data[f"{ci}.tok"][r, :n].tolist()
             assert np.array_equal(out[r, cols].numpy(), data[f"{ci}.val"][r, :n])
+
+
+def test_beam_oracle_reproduces_generate_on_a_ragged_trie_in_every_stopping_mode():
+    """Items of 1..4 levels: EOS arrives at different steps, finished beams compete with running ones.
+    The oracle loop (raw logits -> log_softmax -> fixed-hint processor -> beam step) returns what
+    generate() returned for early_stopping False / True / "never" and four length penalties."""
+    from helpers import ragged_beam_cases
+
+    data, meta, seqs = ragged_beam_cases()
+    prefix, eos, pad = meta["prefix"], meta["eos"], meta["pad"]
+    prompts = torch.from_numpy(data["prompts"])
+    get = oproc.DictTrie(seqs).get
+    assert len(meta["cases"]) == 24
+    for name, info in meta["cases"].items():
+        K = info["K"]
+        proc = oproc.RefFixedHintConstrainedLogitsProcessor(get, K, 3, prefix, eos)
+        logits = [torch.from_numpy(data[f"{name}.logits.{t}"]) for t in range(info["steps"])]
+        state, _ = obeam.ref_constrained_beam_search(
+            lambda step, flat: logits[step], proc, prompts, K, info["max_new_tokens"], eos, pad,
+            info["length_penalty"], info["early_stopping"])
+        assert state.cur_len - prompts.shape[1] == info["steps"], f"{name}: loop length"
+        seqs_o, scores_o, bidx_o = state.finalize()
+        want_scores = torch.from_numpy(data[f"{name}.sequences_scores"])
+        want_seqs = torch.from_numpy(data[f"{name}.sequences"])
+        want_bidx = torch.from_numpy(data[f"{name}.beam_indices"])
+        live = want_scores > -1.0e8
+        w, bw = min(seqs_o.shape[1], want_seqs.shape[1]), min(bidx_o.shape[1], want_bidx.shape[1])
+        assert torch.equal(scores_o[live], want_scores[live]), name
+        assert torch.equal(seqs_o[:, :w][live], want_seqs[:, :w][live]), name
+        assert torch.equal(bidx_o[:, :bw].long()[live], want_bidx[:, :bw].long()[live]), name
