@@ -199,7 +199,7 @@ def time_processor_surface(args, wl, device, calls=10):
                 lib.grx_timing_enable(1)
             if hasattr(proc, "reset"):
                 proc.count = 1
-            proc(ids, x, out=res)
+            proc.call_into(ids, x, res)
         torch.cuda.synchronize()
         tot, n = C.c_double(), C.c_int32()
         _lib.check(lib.grx_timing_read(C.byref(tot), C.byref(n)))

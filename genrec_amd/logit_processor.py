@@ -213,14 +213,18 @@ class _TrieConstrainedBase(LogitsProcessor):
         return t.device.index if t.device.index is not None else torch.cuda.current_device()
 
     # -- the processor surface -----------------------------------------------------------
-    def __call__(self, input_ids: torch.LongTensor, scores: torch.FloatTensor,
-                 out: Optional[torch.Tensor] = None) -> torch.FloatTensor:
+    def __call__(self, input_ids: torch.LongTensor, scores: torch.FloatTensor) -> torch.FloatTensor:
         """``log_softmax(scores) + mask`` as a new [rows, vocab] tensor of the dtype of ``scores``
-        (logit_processor.py:29-49 / fixed_hint_logit_processor.py:79-96).
+        (logit_processor.py:29-49 / fixed_hint_logit_processor.py:79-96).  The signature stays
+        exactly (input_ids, scores): ``LogitsProcessorList`` inspects it and demands keyword
+        arguments for anything more."""
+        return self.call_into(input_ids, scores, None)
 
-        ``out`` is an extension: a caller-owned result tensor (fp32 or the dtype of
-        ``scores``; rows may be padded, i.e. ``out.stride(0) >= vocab``), which saves the
-        allocation and lets bf16 logits produce fp32 log-probs."""
+    def call_into(self, input_ids: torch.LongTensor, scores: torch.FloatTensor,
+                  out: Optional[torch.Tensor]) -> torch.FloatTensor:
+        """``__call__`` writing into ``out`` (extension): a caller-owned result tensor, fp32 or the
+        dtype of ``scores``; rows may be padded (``out.stride(0) >= vocab``).  Saves the allocation
+        and lets bf16 logits produce fp32 log-probs."""
         rows, ids_keep, scores_keep = self._rows(input_ids, scores)
         index = self._device_index(scores_keep)
         if out is None:

@@ -211,6 +211,87 @@ def test_fused_loop_on_a_ragged_trie_in_every_stopping_mode():
         assert float((got_scores[live] - want_scores[live]).abs().max()) <= SCORE_TOL, name
 
 
+@pytest.mark.parametrize("kind", ["count", "fixed"])
+def test_processors_drop_into_transformers_generate_on_the_gpu(kind):
+    """The unmodified HF loop on cuda:0 (tiny random Qwen2) with our processor in its
+    LogitsProcessorList, as evaluate.py:363-371 / MIMIGenRec.py:79 call it, against the same loop with
+    the CPU restatement of the reference processor: same sequences and beam indices, scores within
+    1e-5, over two consecutive generate() calls (counter reset between them as evaluate.py:358-361 does)."""
+    from transformers import LogitsProcessor, LogitsProcessorList, Qwen2Config, Qwen2ForCausalLM
+
+    from oracle.processors import (DictTrie, RefConstrainedLogitsProcessor,
+                                   RefFixedHintConstrainedLogitsProcessor)
+
+    from genrec_amd.fixed_hint_logit_processor import FixedHintConstrainedLogitsProcessor
+    from genrec_amd.logit_processor import ConstrainedLogitsProcessor
+    from genrec_amd.trie import FlatTrie, create_prefix_allowed_tokens_fn
+
+    dev = _dev()
+    data, meta = load_npz("beams.npz")
+    prefix, eos, pad, V = meta["prefix"], meta["eos"], meta["pad"], meta["V"]
+    seqs = data["trie_sequences"].tolist()
+    fn = create_prefix_allowed_tokens_fn(FlatTrie(seqs), prefix)
+    K = 8
+    torch.manual_seed(11)
+    cfg = Qwen2Config(vocab_size=V, hidden_size=32, intermediate_size=64, num_hidden_layers=2,
+                      num_attention_heads=2, num_key_value_heads=2, max_position_embeddings=128,
+                      eos_token_id=eos, pad_token_id=pad, bos_token_id=None, tie_word_embeddings=False)
+    model = Qwen2ForCausalLM(cfg).eval()
+    with torch.no_grad():
+        for p in model.parameters():
+            p.mul_(6.0)
+    model = model.to(dev)
+
+    class OnCpu(LogitsProcessor):
+        """The oracle works on CPU tensors; the HF loop hands over device tensors."""
+
+        def __init__(self, inner):
+            self.inner = inner
+
+        @property
+        def count(self):
+            return self.inner.count
+
+        @count.setter
+        def count(self, v):
+            self.inner.count = v
+
+        def __call__(self, input_ids, scores):
+            return self.inner(input_ids.cpu(), scores.float().cpu()).to(scores.device)
+
+    get = DictTrie(seqs).get
+    if kind == "count":
+        ours = ConstrainedLogitsProcessor(fn, K, 3, None, eos)           # evaluate.py:283-288 passes no prefix_ids
+        ref = OnCpu(RefConstrainedLogitsProcessor(get, K, 3, None, eos))
+    else:
+        ours = FixedHintConstrainedLogitsProcessor(fn, K, 3, prefix, eos)
+        ref = OnCpu(RefFixedHintConstrainedLogitsProcessor(get, K, 3, prefix, eos))
+    g = torch.Generator().manual_seed(3)
+    for round_ in range(2):
+        prompts = torch.cat([torch.randint(20, 90, (3, 7), generator=g), torch.tensor([prefix] * 3)], dim=1).to(dev)
+        outs = []
+        for proc in (ours, ref):
+            if hasattr(proc, "count"):
+                proc.count = 0
+            with torch.no_grad():
+                outs.append(model.generate(
+                    prompts, attention_mask=torch.ones_like(prompts), logits_processor=LogitsProcessorList([proc]),
+                    num_beams=K, num_return_sequences=K, max_new_tokens=8, do_sample=False, length_penalty=0.0,
+                    eos_token_id=eos, pad_token_id=pad, output_scores=True, return_dict_in_generate=True))
+        a, b = outs
+        live = b.sequences_scores > LIVE
+        assert int(live.sum()) >= 3 * K // 2
+        assert torch.equal(a.sequences[live], b.sequences[live])
+        assert torch.equal(a.beam_indices[live], b.beam_indices[live])
+        assert float((a.sequences_scores[live] - b.sequences_scores[live]).abs().max()) <= SCORE_TOL
+        assert len(a.scores) == len(b.scores)
+        for sa, sb in zip(a.scores, b.scores):  # the processor outputs HF recorded at every step
+            fin = torch.isfinite(sb)
+            assert torch.equal(torch.isfinite(sa), fin)
+            assert float((sa[fin] - sb[fin]).abs().max()) <= SCORE_TOL
+    ours.check_errors()
+
+
 def test_beam_step_large_random_against_oracle():
     """Synthetic candidates at rollout scale (K=16 and K=50, fan-out up to 242): exact top-2K order."""
     from oracle.beam import RefBeamSearch

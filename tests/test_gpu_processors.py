@@ -263,7 +263,7 @@ def test_ragged_vocab_widths_against_oracle(V, dtype):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_caller_owned_output_padded_rows_and_fp32_results(dtype):
-    """`out=`: padded output rows (row-wise fill path) and fp32 log-probs from bf16 logits equal the
+    """`call_into`: padded output rows (row-wise fill path) and fp32 log-probs from bf16 logits equal the
     values of the plain call / the candidates."""
     from genrec_amd.logit_processor import ConstrainedLogitsProcessor
     from genrec_amd.trie import FlatTrie, create_prefix_allowed_tokens_fn
@@ -283,7 +283,7 @@ def test_caller_owned_output_padded_rows_and_fp32_results(dtype):
     for pad in (0, 8, 5):  # 5 breaks the 16-byte row alignment: element-wise path
         backing = torch.full((R, V + pad), 7.0, dtype=dtype, device=dev)
         proc.count = 1
-        got = proc(ids, scores, out=backing[:, :V])
+        got = proc.call_into(ids, scores, backing[:, :V])
         assert got.data_ptr() == backing.data_ptr()
         if pad == 5:  # other summation order: same values up to rounding
             assert torch.equal(torch.isfinite(got), torch.isfinite(plain))
@@ -295,7 +295,7 @@ def test_caller_owned_output_padded_rows_and_fp32_results(dtype):
             assert bool((backing[:, V:] == 7.0).all()), "padding columns must stay untouched"
     out32 = torch.empty((R, V), dtype=torch.float32, device=dev)
     proc.count = 1
-    proc(ids, scores, out=out32)
+    proc.call_into(ids, scores, out32)
     proc.count = 1
     cand = proc.candidates(ids, scores)
     finite = torch.isfinite(out32)
@@ -304,7 +304,7 @@ def test_caller_owned_output_padded_rows_and_fp32_results(dtype):
     assert torch.equal(out32[finite], cand.logp[valid])  # same fp32 values, row-major token order
     assert torch.equal(finite, torch.isfinite(plain))
     with pytest.raises(ValueError):
-        proc(ids, scores, out=torch.empty((R, V), dtype=torch.float16, device=dev))
+        proc.call_into(ids, scores, torch.empty((R, V), dtype=torch.float16, device=dev))
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
