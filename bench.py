@@ -330,7 +330,7 @@ def main() -> None:
             "config": {
                 "workload": f"C2: {args.trie} 4-256 SID trie, {args.processor} processor, beam={args.beams}, "
                             f"batch={args.batch} per GPU (R={R} rows), V={wl['V']}, {args.dtype} logits N(0,16); "
-                            f"fused step = resolve + masked log-softmax (compact) + beam step; every "
+                            f"fused step = row planning + masked log-softmax (compact candidates) + beam step; every "
                             f"{wl['levels']} steps one rollout is scored (rule+NDCG rewards, reward all-gather, "
                             f"group advantages)",
                 "rows_per_step_per_gpu": R,
