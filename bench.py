@@ -45,7 +45,13 @@ def build_workload(args, device):
     from helpers import write_index_file
 
     tmp = tempfile.mkdtemp(prefix="genrec_bench_")
-    path = write_index_file(args.trie, tmp)
+    if args.trie.startswith("cb"):  # codebook sweep: synthetic 4-level index with the given codebook size
+        from genrec_amd.synth import synthetic_index, write_index
+
+        path = write_index(os.path.join(tmp, f"{args.trie}.index.json"),
+                           synthetic_index(9922, 4, int(args.trie[2:]), seed=0))
+    else:
+        path = write_index_file(args.trie, tmp)
     tok = SidTokenizer.from_index(path)
     trie, suffix, pidx = build_trie_from_index(path, tok, prefix=ASSISTANT_PREFIX)
     fn = create_prefix_allowed_tokens_fn(trie, suffix)
@@ -246,7 +252,8 @@ def main() -> None:
     ap.add_argument("--batch", type=int, default=512, help="prompt groups per GPU")
     ap.add_argument("--beams", type=int, default=16)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "fp16"])
-    ap.add_argument("--trie", default="Instruments")
+    ap.add_argument("--trie", default="Instruments",
+                    help="Industrial_and_Scientific | Instruments | Games | Arts | cb<codebook size> (synthetic)")
     ap.add_argument("--processor", default="count", choices=["count", "fixed_hint"])
     ap.add_argument("--prompt-len", type=int, default=61)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -328,7 +335,8 @@ def main() -> None:
             "dtype": args.dtype,
             "data": "synthetic",
             "config": {
-                "workload": f"C2: {args.trie} 4-256 SID trie, {args.processor} processor, beam={args.beams}, "
+                "workload": f"{'C2: ' if (args.trie, args.processor, args.batch) == ('Instruments', 'count', 512) else ''}"
+                            f"{args.trie} SID trie, {args.processor} processor, beam={args.beams}, "
                             f"batch={args.batch} per GPU (R={R} rows), V={wl['V']}, {args.dtype} logits N(0,16); "
                             f"fused step = row planning + masked log-softmax (compact candidates) + beam step; every "
                             f"{wl['levels']} steps one rollout is scored (rule+NDCG rewards, reward all-gather, "

@@ -13,7 +13,6 @@
 #define BS_WAVES (BS_THREADS / GRX_WAVE)
 #define BS_MAXK 256
 #define BS_MAXKEEP 512
-#define BS_LDS_KEYS_MAX 16384  // 128 KiB of staged 64-bit keys at most
 #define BS_SURV_CAP 1024       // candidates ranked pairwise after the threshold cut
 #define BS_PREFETCH 16         // beams whose candidate rows are fetched in the opening batch of loads
 #define BS_TAIL_K 64           // beams / positions per row of the sequence tails staged in LDS
@@ -23,7 +22,6 @@ struct BeamDerived {
     float fin_div;    // (cur_len + 1 - prompt_len) ** length_penalty
     float heur_div;   // best_hypothetical_length ** length_penalty
     int reg_keys;     // every candidate slot is covered by the opening batch of loads: keys stay in registers
-    int lds_keys;     // capacity of the dynamic LDS key buffer (0: rescan global memory)
     int tails_in_lds; // the re-ordered parts of the sequence / parent rows fit the LDS tail buffers
 };
 
@@ -52,8 +50,8 @@ extern "C" __attribute__((visibility("default"))) int grx_debug_read_stamps(unsi
 // Layout: the candidates of a group are the K x cmax block behind its first row;
 // slot c = beam * cmax + position holds a key, or 0 when position >= count[beam].
 __global__ __launch_bounds__(BS_THREADS) void beam_step_kernel(grx_beam_step_args a, BeamDerived d) {
-    extern __shared__ unsigned long long s_keys[];
     __shared__ int s_cnt[BS_MAXK];
+    __shared__ int s_base[BS_MAXK + 1];
     __shared__ float s_runin[BS_MAXK];
     __shared__ unsigned char s_fdone_in[BS_MAXK];
     __shared__ unsigned long long s_tmax[BS_THREADS];
@@ -88,17 +86,18 @@ __global__ __launch_bounds__(BS_THREADS) void beam_step_kernel(grx_beam_step_arg
     const int w_run = a.cur_len - a.copy_from;        // positions of a running row that move with a re-order
     const int w_fin = a.cur_len + 1 - a.copy_from;    // ... of a finished row
     const int slots = K * cmax;
-    const bool staged = slots <= d.lds_keys;
     STAMP(0);
 
     // ---- phase A: every global read the step needs is issued before the first wait.
     // Thread t prefetches column t of the first BS_PREFETCH beams (coalesced rows).
     grx_cand pre[BS_PREFETCH];
     const grx_cand* __restrict__ g_cand = a.cand + row0 * a.cand_stride;
+    if (d.reg_keys) {
 #pragma unroll
-    for (int u = 0; u < BS_PREFETCH; ++u) {
-        // entries past a beam's count hold stale values; they are masked below
-        pre[u] = g_cand[(u < K && tid < cmax) ? (int64_t)u * a.cand_stride + 1 + tid : 0];
+        for (int u = 0; u < BS_PREFETCH; ++u) {
+            // entries past a beam's count hold stale values; they are masked below
+            pre[u] = g_cand[(u < K && tid < cmax) ? (int64_t)u * a.cand_stride + 1 + tid : 0];
+        }
     }
     for (int k = tid; k < K; k += BS_THREADS) {
         s_cnt[k] = g_cand[(int64_t)k * a.cand_stride].x;
@@ -205,23 +204,32 @@ __global__ __launch_bounds__(BS_THREADS) void beam_step_kernel(grx_beam_step_arg
             for (int j = M + tid; j < n_keep; j += BS_THREADS) emit(j, 0);
             selected = true;
         }
-    } else if (staged) {
-        // slot layout in LDS: beam-major, s_keys[k * cmax + i]
-#pragma unroll
-        for (int u = 0; u < BS_PREFETCH; ++u) {
-            if (u < K && tid < cmax) s_keys[u * cmax + tid] = key_at(u, tid, __int_as_float(pre[u].y), pre[u].x);
+    } else {
+        // Wider groups: two passes over the existing candidates straight from global memory (they were
+        // written a moment ago and sit in L2) -- per-thread maxima and threshold first, survivors second.
+        // Candidate c of the group is entry c - s_base[k] of beam k, the largest k with s_base[k] <= c.
+        for (int k = tid; k <= K; k += BS_THREADS) {
+            int acc = 0;
+            for (int j = 0; j < k; ++j) acc += s_cnt[j] < cmax ? s_cnt[j] : cmax;
+            s_base[k] = acc;
         }
-        for (int k = 0; k < K; ++k) {  // whatever the opening batch did not cover
-            for (int i = tid + (k < BS_PREFETCH ? BS_THREADS : 0); i < cmax; i += BS_THREADS) {
-                const grx_cand e = g_cand[(int64_t)k * a.cand_stride + 1 + i];
-                s_keys[k * cmax + i] = key_at(k, i, __int_as_float(e.y), e.x);
-            }
-        }
-        STAMP(3);
         __syncthreads();
-        unsigned long long tmax = 0;  // maximum over a strided slice of the slots
+        const int total = s_base[K];
+        auto packed_key = [&](int c) -> unsigned long long {
+            int lo = 0, hi = K;
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (s_base[mid] <= c) lo = mid; else hi = mid;
+            }
+            const grx_cand e = g_cand[(int64_t)lo * a.cand_stride + 1 + (c - s_base[lo])];
+            return make_key(__int_as_float(e.y) + s_runin[lo], (uint32_t)lo, (uint32_t)e.x);
+        };
+        unsigned long long tmax = 0;
 #pragma unroll 4
-        for (int c = tid; c < slots; c += BS_THREADS) tmax = s_keys[c] > tmax ? s_keys[c] : tmax;
+        for (int c = tid; c < total; c += BS_THREADS) {
+            const unsigned long long kv = packed_key(c);
+            tmax = kv > tmax ? kv : tmax;
+        }
         s_tmax[tid] = tmax;
         STAMP(4);
         __syncthreads();
@@ -235,9 +243,9 @@ __global__ __launch_bounds__(BS_THREADS) void beam_step_kernel(grx_beam_step_arg
         __syncthreads();
         const unsigned long long thresh = s_thresh;
 #pragma unroll 4
-        for (int c = tid; c < slots; c += BS_THREADS) {
-            const unsigned long long kv = s_keys[c];
-            if (kv != 0 && kv >= thresh) {
+        for (int c = tid; c < total; c += BS_THREADS) {
+            const unsigned long long kv = packed_key(c);
+            if (kv >= thresh) {
                 const int at = atomicAdd(&s_nsurv, 1);
                 if (at < BS_SURV_CAP) s_surv[at] = kv;
             }
@@ -263,16 +271,9 @@ __global__ __launch_bounds__(BS_THREADS) void beam_step_kernel(grx_beam_step_arg
         for (int j = 0; j < n_keep; ++j) {
             unsigned long long best = 0;
             if (prev != 0) {
-                if (staged) {
-                    for (int c = tid; c < slots; c += BS_THREADS) {
-                        const unsigned long long kv = s_keys[c];
-                        if (kv < prev && kv > best) best = kv;
-                    }
-                } else {
-                    for (int c = tid; c < slots; c += BS_THREADS) {
-                        const unsigned long long kv = key_of(c);
-                        if (kv < prev && kv > best) best = kv;
-                    }
+                for (int c = tid; c < slots; c += BS_THREADS) {
+                    const unsigned long long kv = key_of(c);
+                    if (kv < prev && kv > best) best = kv;
                 }
                 best = wave_max_u64(best);
                 if (lane == 0) s_red[j & 1][wave] = best;
@@ -499,17 +500,10 @@ extern "C" int grx_beam_step(const grx_beam_step_args* args, void* stream) {
     const int hyp = (a.early_stopping == 2 && a.length_penalty > 0.0f) ? (a.max_length - a.prompt_len)
                                                                        : (a.cur_len + 1 - a.prompt_len);
     d.heur_div = (float)pow((double)hyp, lp);
-    const int64_t slots = (int64_t)a.K * a.cmax;
     d.reg_keys = (a.K <= BS_PREFETCH && a.cmax <= BS_THREADS && a.n_keep <= GRX_WAVE) ? 1 : 0;
-    d.lds_keys = (!d.reg_keys && slots <= BS_LDS_KEYS_MAX) ? (int)slots : 0;
     d.tails_in_lds = (a.K <= BS_TAIL_K && a.cur_len + 1 - a.copy_from <= BS_TAIL_W &&
                       a.cur_len - a.prompt_len + 1 <= BS_TAIL_W) ? 1 : 0;
-    const size_t lds_bytes = (size_t)d.lds_keys * sizeof(unsigned long long);
-    if (lds_bytes > 32 * 1024) {
-        GRX_CHECK_HIP(hipFuncSetAttribute((const void*)beam_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (int)lds_bytes));
-    }
-    hipLaunchKernelGGL(beam_step_kernel, dim3(a.B), dim3(BS_THREADS), lds_bytes, (hipStream_t)stream, a, d);
+    hipLaunchKernelGGL(beam_step_kernel, dim3(a.B), dim3(BS_THREADS), 0, (hipStream_t)stream, a, d);
     GRX_CHECK_HIP(hipGetLastError());
     return GRX_OK;
 }

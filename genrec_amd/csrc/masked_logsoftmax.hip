@@ -108,6 +108,16 @@ __device__ __forceinline__ void fill_store(u32x4* p, const u32x4& v) {
 #endif
 }
 typedef int i32x2 __attribute__((ext_vector_type(2)));
+// Two adjacent entries (16 bytes; p is 16-byte aligned).
+__device__ __forceinline__ void cand_store2(grx_cand* p, const grx_cand& v0, const grx_cand& v1) {
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    const i32x4 w = {v0.x, v0.y, v1.x, v1.y};
+#if MLS_NTST
+    __builtin_nontemporal_store(w, reinterpret_cast<i32x4*>(p));
+#else
+    *reinterpret_cast<i32x4*>(p) = w;
+#endif
+}
 __device__ __forceinline__ void cand_store(grx_cand* p, const grx_cand& v) {
     const i32x2 w = {v.x, v.y};
 #if MLS_NTST
@@ -286,10 +296,9 @@ __global__ __launch_bounds__(MLS_THREADS) void masked_lsm_kernel(MlsArgs a) {
         c_n = 0;
     }
 
-    // Gather the first allowed logits now so they overlap the stream.  Slot k of a
-    // thread belongs to compact entry e = tid + k * threads, i.e. candidate e - 1
-    // (entry 0 is the row header), so that each store instruction of the epilogue
-    // covers whole 128-byte lines.
+    // Gather the first allowed logits now so they overlap the stream.  In compact mode
+    // a thread owns MLS_EARLY adjacent entries e = tid * MLS_EARLY + k, i.e. candidates
+    // e - 1 (entry 0 is the row header), which it later writes with one 16-byte store.
     // A split row is emitted by whichever workgroup finishes last, which gathers then.
     constexpr int SHIFT = (OUT == OUT_COMPACT) ? 1 : 0;
     int e_tok[MLS_EARLY];
@@ -297,12 +306,16 @@ __global__ __launch_bounds__(MLS_THREADS) void masked_lsm_kernel(MlsArgs a) {
     auto gather = [&]() {
 #pragma unroll
         for (int k = 0; k < MLS_EARLY; ++k) {
-            const int i = tid + k * MLS_THREADS - SHIFT;
+            const int i = (OUT == OUT_COMPACT) ? tid * MLS_EARLY + k - SHIFT : tid + k * MLS_THREADS;
             e_tok[k] = -1;
             e_val[k] = 0.f;
             if (i >= 0 && i < c_n) {
                 e_tok[k] = (code == GRX_RES_EOS) ? a.eos : a.tok[c_off + i];
+#ifdef MLS_ABL_NOGATHER
+                e_val[k] = 0.f;
+#else
                 e_val[k] = E::to_float(row[e_tok[k]]);
+#endif
             }
         }
     };
@@ -485,28 +498,38 @@ __global__ __launch_bounds__(MLS_THREADS) void masked_lsm_kernel(MlsArgs a) {
         // Whole 128-byte lines only: header + candidates + zero padding up to the next 16 entries.
         grx_cand* __restrict__ crow = a.cand + (int64_t)r * a.cand_stride;
         const int n_line = ((c_n + 1 + 15) / 16) * 16;
-#pragma unroll
-        for (int k = 0; k < MLS_EARLY; ++k) {
-            const int e = tid + k * MLS_THREADS;
-            if (e < n_line) {
-                grx_cand v = {0, 0};
-                if (e == 0) {
-                    v.x = c_n;
-                    v.y = __float_as_int(tot.m + log_s + lse2);
-                } else if (e - 1 < c_n) {
-                    v.x = e_tok[k];
-                    v.y = __float_as_int(final_logp(e_tok[k], e_val[k] - tot.m));
-                }
-                cand_store(crow + e, v);
+        static_assert(MLS_EARLY == 2, "the compact epilogue pairs two 8-byte entries per 16-byte store");
+        auto entry = [&](int e, int tokv, float xm) {  // compact entry e of this row
+            grx_cand v = {0, 0};
+            if (e == 0) {
+                v.x = c_n;
+                v.y = __float_as_int(tot.m + log_s + lse2);
+            } else if (e - 1 < c_n) {
+                v.x = tokv;
+                v.y = __float_as_int(final_logp(tokv, xm));
+            }
+            return v;
+        };
+        {
+            const int e = tid * 2;
+#ifdef MLS_ABL_NOSTORE
+            if (e == 0) {
+#else
+            if (e < n_line) {  // n_line is even, so the pair is inside the row
+#endif
+                cand_store2(crow + e, entry(e, e_tok[0], e_val[0] - tot.m), entry(e + 1, e_tok[1], e_val[1] - tot.m));
             }
         }
-        for (int e = tid + MLS_EARLY * MLS_THREADS; e < n_line; e += MLS_THREADS) {
-            grx_cand v = {0, 0};
-            if (e - 1 < c_n) {
-                v.x = a.tok[c_off + e - 1];  // an EOS-only row has c_n == 1 and never gets here
-                v.y = __float_as_int(final_logp(v.x, E::to_float(row[v.x]) - tot.m));
-            }
-            cand_store(crow + e, v);
+#ifdef MLS_ABL_NOSTORE
+        for (int e = (tid + MLS_THREADS) * 2; e < 0; e += MLS_THREADS * 2) {
+#else
+        for (int e = (tid + MLS_THREADS) * 2; e < n_line; e += MLS_THREADS * 2) {
+#endif
+            // an EOS-only row has c_n == 1 and never gets here
+            const int t0 = e - 1 < c_n ? a.tok[c_off + e - 1] : 0, t1 = e < c_n ? a.tok[c_off + e] : 0;
+            const float x0 = e - 1 < c_n ? E::to_float(row[t0]) - tot.m : 0.f;
+            const float x1 = e < c_n ? E::to_float(row[t1]) - tot.m : 0.f;
+            cand_store2(crow + e, entry(e, t0, x0), entry(e + 1, t1, x1));
         }
     } else {
         OT* __restrict__ orow = reinterpret_cast<OT*>(a.out) + (int64_t)r * a.out_stride;

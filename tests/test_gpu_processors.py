@@ -416,7 +416,8 @@ def test_fused_repetition_penalty_matches_the_transformers_chain():
             fin = torch.isfinite(dense)
             assert torch.equal(fin.sum(dim=1), n.long())
             if dtype == torch.float32:
-                assert torch.equal(dense[fin], got)  # dense and compact forms carry the same values
+                # dense and compact forms carry the same values (up to how each instantiation fuses a multiply-add)
+                assert float((dense[fin] - got).abs().max()) <= 4e-6
     with pytest.raises(ValueError):
         ConstrainedLogitsProcessor(fn, K, pidx, None, eos, repetition_penalty=0.0)
 

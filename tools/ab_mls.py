@@ -30,7 +30,14 @@ def main():
     dtype = {"bf16": torch.bfloat16, "fp32": torch.float32}[os.environ.get("AB_DTYPE", "bf16")]
     step = int(os.environ.get("AB_STEP", 1))
     dev = torch.device("cuda", 0)
-    path = write_index_file("Instruments", tempfile.mkdtemp())
+    trie_name = os.environ.get("AB_TRIE", "Instruments")
+    if trie_name.startswith("cb"):
+        from genrec_amd.synth import synthetic_index, write_index
+
+        path = write_index(os.path.join(tempfile.mkdtemp(), "cb.index.json"),
+                           synthetic_index(9922, 4, int(trie_name[2:]), seed=0))
+    else:
+        path = write_index_file(trie_name, tempfile.mkdtemp())
     tok = SidTokenizer.from_index(path)
     trie, suffix, pidx = build_trie_from_index(path, tok, prefix=ASSISTANT_PREFIX)
     V = tok.vocab_size_padded
@@ -85,7 +92,8 @@ def main():
                 if ref is None:
                     ref = got
                 else:
-                    if "abl" in name: continue
+                    if "abl" in name:
+                        continue
                     assert torch.equal(got[0], ref[0]), name
                     m = torch.arange(cmax, device=dev)[None, :] < ref[0][:, None]
                     assert torch.equal(got[1][m], ref[1][m]), name
