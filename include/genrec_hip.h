@@ -164,9 +164,8 @@ GRX_API int grx_constrained_logsoftmax(const grx_trie* trie, grx_state* state, c
  * The row stride (in entries) is a multiple of 16 and at least cmax + 1, and the
  * buffer is 128-byte aligned, so every row starts on its own 128-byte line and is
  * written in whole lines (entries between count + 1 and the next multiple of 16
- * are zero-filled; anything beyond is left untouched).  Whole-line writes matter:
- * masked partial-line writes into HBM cost a read-modify-write each and measurably
- * slow the logit stream they are interleaved with.
+ * are zero-filled; anything beyond is left untouched): no store ever covers part
+ * of a memory line.
  */
 typedef struct grx_cand {
     int32_t x;
@@ -190,10 +189,12 @@ GRX_API int grx_constrained_candidates(const grx_trie* trie, grx_state* state, c
 
 /*
  * Kernel timing for benchmarks (no counterpart in the reference).  While
- * enabled, the two calls above bracket their streaming kernel -- and only that
- * kernel -- with HIP events on the caller's stream (up to 4096 launches per
- * enable).  grx_timing_read synchronises on the recorded events and returns
- * the summed kernel time in milliseconds and the number of launches.
+ * enabled, the two calls above attach HIP events to the dispatch of their
+ * streaming kernel (compact form) or to the fill kernel's start and the
+ * streaming kernel's end (dense form), up to 4096 calls per enable; the row
+ * planning kernel is not included.  grx_timing_read synchronises on the
+ * recorded events and returns the summed time in milliseconds and the number
+ * of calls.  Process-wide and not thread-safe: a measurement hook, not an API.
  */
 GRX_API int grx_timing_enable(int on);
 GRX_API int grx_timing_read(double* total_ms, int32_t* launches);

@@ -32,27 +32,10 @@ def main():
             _lib._lib = h
             try:
                 st = BeamSearchState(prompts, K, 64 + 6, 151645, 151643, 1.0, False, shared_prompt=True)
-                # capture the argument blocks of two consecutive steps, then replay them from a tight loop
-                captured = []
-                orig = h.grx_beam_step
-
-                def spy(args_ref, stream):
-                    blk = _lib.GrxBeamStepArgs()
-                    C.memmove(C.byref(blk), args_ref, C.sizeof(blk))
-                    captured.append(blk)
-                    return orig(args_ref, stream)
-
+                # two real steps bring the state to depth 2; the timing loop then replays hand-built
+                # argument blocks (ping-pong between the double buffers) without Python in between
                 st.reset(prompts)
                 for _ in range(2):
-                    a = _lib.GrxBeamStepArgs()
-                    # run one step through the normal path while recording its args
-                    import types
-                    real_step = h.grx_beam_step
-                    class Rec:
-                        pass
-                    st_step_args = {}
-                    def rec_check(status):
-                        return _lib.check(status)
                     st.step(cand, V)
                 ts = []
                 stream = torch.cuda.current_stream().cuda_stream
