@@ -100,20 +100,22 @@ class Rollout:
         self.rpf = torch.empty((self.R, 2), dtype=torch.float32, device=device)
         self.state = None
         self.depth = 0
+        self.plan_ahead = not getattr(args, "no_plan_ahead", False)
         self.prompt_rows = wl["prompts"].repeat_interleave(args.beams, dim=0).contiguous()
 
     def new_generation(self):
         from genrec_amd.beam import BeamSearchState
 
         wl, a = self.wl, self.args
+        if hasattr(wl["proc"], "reset"):
+            wl["proc"].count = 0  # no error read-back inside the timed loop
+        planner = wl["proc"] if self.plan_ahead else None
         if self.state is None:
             self.state = BeamSearchState(self.prompt_rows, a.beams, self.prompt_rows.shape[1] + wl["levels"] + 1,
                                          wl["tok"].eos_token_id, wl["tok"].pad_token_id, 1.0, False,
-                                         shared_prompt=True)
+                                         shared_prompt=True, planner=planner)
         else:
-            self.state.reset(self.prompt_rows)  # full re-initialisation from the prompts, one launch
-        if hasattr(wl["proc"], "reset"):
-            wl["proc"].count = 0  # no error read-back inside the timed loop
+            self.state.reset(self.prompt_rows, planner)  # full re-initialisation from the prompts
         self.depth = 0
 
     def step(self):
@@ -124,7 +126,9 @@ class Rollout:
             self.new_generation()
         flat = self.state.flat_running_sequences()
         wl["proc"].candidates_into(flat, wl["logits"][self.depth], self.cand)
-        self.state.step(self.cand, wl["V"])
+        # the beam kernel plans the next processor call, except after the last level of a generation
+        planner = wl["proc"] if (self.plan_ahead and self.depth + 1 < wl["levels"]) else None
+        self.state.step(self.cand, wl["V"], planner)
         self.depth += 1
 
     def score(self):
@@ -268,6 +272,8 @@ def main() -> None:
     ap.add_argument("--cpu-groups", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-processor-surface", action="store_true", help="skip the dense [R, V] mode measurement")
+    ap.add_argument("--no-plan-ahead", action="store_true",
+                    help="let every processor call run its own row planning kernel (as under the plain HF loop)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="leave the per-launch HIP events out")
     args = ap.parse_args()
 

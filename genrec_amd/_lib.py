@@ -59,6 +59,8 @@ class GrxRows(C.Structure):
         ("scores_stride", C.c_int64),
         ("V", C.c_int32),
         ("dtype", C.c_int32),
+        ("planned", C.c_int32),
+        ("reserved", C.c_int32),
     ]
 
 
@@ -71,6 +73,16 @@ class GrxConstraint(C.Structure):
         ("prefix_ids", C.c_int64 * GRX_MAX_PREFIX),
         ("repetition_penalty", C.c_float),
         ("penalty_skip", C.c_int32),
+    ]
+
+
+class GrxPlanRequest(C.Structure):
+    _fields_ = [
+        ("trie", C.c_void_p),
+        ("state", C.c_void_p),
+        ("con", C.c_void_p),
+        ("workspace", C.c_void_p),
+        ("workspace_bytes", C.c_size_t),
     ]
 
 
@@ -110,6 +122,7 @@ class GrxBeamStepArgs(C.Structure):
         ("topk_token", C.c_void_p),
         ("topk_hit", C.c_void_p),
         ("next_parent", C.c_void_p),
+        ("plan_next", C.c_void_p),
     ]
 
 
@@ -130,6 +143,7 @@ class GrxBeamInitArgs(C.Structure):
         ("fin_bidx", C.c_void_p * 2),
         ("fin_done", C.c_void_p * 2),
         ("unsat", C.c_void_p),
+        ("plan_next", C.c_void_p),
     ]
 
 

@@ -40,7 +40,7 @@ class BeamSearchState:
 
     def __init__(self, input_ids: torch.Tensor, num_beams: int, max_length: int, eos_token_id: Optional[int],
                  pad_token_id: Optional[int] = None, length_penalty: float = 1.0, early_stopping=False,
-                 shared_prompt: bool = True):
+                 shared_prompt: bool = True, planner=None):
         _lib.require_cuda(input_ids, "input_ids")
         R, cur_len = input_ids.shape
         if R % num_beams:
@@ -77,11 +77,15 @@ class BeamSearchState:
         self.fin_done = pair((B, K), torch.uint8)
         self.unsat = torch.empty(B, dtype=torch.uint8, device=dev)
         self._step_out = None
-        self.reset(input_ids)
+        self.reset(input_ids, planner)
 
-    def reset(self, input_ids: torch.Tensor) -> None:
+    def reset(self, input_ids: torch.Tensor, planner=None) -> None:
         """Start a new search from ``input_ids`` [B*K, prompt_len] (same shape as at
-        construction) in the existing buffers: one kernel launch, no allocation."""
+        construction) in the existing buffers: one kernel launch, no allocation.
+
+        ``planner`` (a genrec_amd processor): also work out the trie node of every prompt row for
+        the processor's next call, which then skips its own planning kernel.  The processor's
+        counter must already be what that call should see (reset it first)."""
         _lib.require_cuda(input_ids, "input_ids")
         if tuple(input_ids.shape) != (self.B * self.K, self.prompt_len):
             raise ValueError("reset() needs input_ids of the shape the state was built for")
@@ -103,11 +107,19 @@ class BeamSearchState:
             a.fin_bidx[h] = self.fin_bidx[h].data_ptr()
             a.fin_done[h] = self.fin_done[h].data_ptr()
         a.unsat = self.unsat.data_ptr()
+        keep = None
+        if planner is not None:
+            req, keep = planner.plan_request(self.device, self.B * self.K)
+            a.plan_next = C.addressof(req)
         index = self.device.index if self.device.index is not None else torch.cuda.current_device()
         with torch.cuda.device(index):
             _lib.check(_lib.lib().grx_beam_init(C.byref(a), _lib.current_stream_ptr(self.device)))
+        del keep
         self.cur = 0  # index of the buffer that holds the current state
         self.cur_len = self.prompt_len
+        if planner is not None:
+            # the plans describe the caller's prompt rows; the running-sequence view holds the same tokens
+            planner.note_planned(self.flat_running_sequences())
 
     # -- views of the current state -------------------------------------------------
     @property
@@ -150,8 +162,10 @@ class BeamSearchState:
             )
         return self._step_out
 
-    def step(self, cand, vocab_size: int) -> BeamStepResult:
-        """Advance by one token from the processor's compact candidates (a ``Candidates`` buffer)."""
+    def step(self, cand, vocab_size: int, planner=None) -> BeamStepResult:
+        """Advance by one token from the processor's compact candidates (a ``Candidates`` buffer).
+        ``planner`` (the processor): the kernel also plans the processor's next call on the new
+        running sequences, so that call starts streaming at once."""
         a = _lib.GrxBeamStepArgs()
         i, o = self.cur, 1 - self.cur
         out = self._outputs()
@@ -175,11 +189,19 @@ class BeamSearchState:
         a.topk_score, a.topk_parent = out.topk_scores.data_ptr(), out.topk_parent.data_ptr()
         a.topk_token, a.topk_hit = out.topk_token.data_ptr(), out.topk_hit.data_ptr()
         a.next_parent = out.next_parent.data_ptr()
+        keep = None
+        plan = planner is not None and self.cur_len + 1 < self.max_length
+        if plan:
+            req, keep = planner.plan_request(self.device, self.B * self.K)
+            a.plan_next = C.addressof(req)
         index = self.device.index if self.device.index is not None else torch.cuda.current_device()
         with torch.cuda.device(index):
             _lib.check(_lib.lib().grx_beam_step(C.byref(a), _lib.current_stream_ptr(self.device)))
+        del keep
         self.cur = o
         self.cur_len += 1
+        if plan:
+            planner.note_planned(self.flat_running_sequences())
         return out
 
     def has_unfinished(self) -> bool:
@@ -226,20 +248,20 @@ def constrained_beam_search(
     Returns ``(state, sequences, sequences_scores, beam_indices)``.
     """
     prompts = input_ids.repeat_interleave(num_beams, dim=0)
+    if hasattr(processor, "reset"):
+        processor.reset()  # before the state is built: its initialisation plans the first call
     state = BeamSearchState(prompts, num_beams, input_ids.shape[1] + max_new_tokens, eos_token_id, pad_token_id,
-                            length_penalty, early_stopping, shared_prompt=True)
+                            length_penalty, early_stopping, shared_prompt=True, planner=processor)
     from .logit_processor import Candidates
 
     cand = Candidates(state.B * num_beams, max(processor.trie.max_fanout, 1), input_ids.device)
-    if hasattr(processor, "reset"):
-        processor.reset()
     step = 0
     next_parent = None
     while True:
         flat = state.flat_running_sequences()
         logits = logits_fn(step, flat, next_parent)
         processor.candidates_into(flat, logits, cand)
-        res = state.step(cand, logits.shape[-1])
+        res = state.step(cand, logits.shape[-1], planner=processor)
         next_parent = res.next_parent
         step += 1
         if max_steps is not None:

@@ -8,6 +8,7 @@
 #include <string.h>
 
 #include "common.h"
+#include "resolve.h"
 
 #define BS_THREADS 256
 #define BS_WAVES (BS_THREADS / GRX_WAVE)
@@ -49,7 +50,8 @@ extern "C" __attribute__((visibility("default"))) int grx_debug_read_stamps(unsi
 
 // Layout: the candidates of a group are the K x cmax block behind its first row;
 // slot c = beam * cmax + position holds a key, or 0 when position >= count[beam].
-__global__ __launch_bounds__(BS_THREADS) void beam_step_kernel(grx_beam_step_args a, BeamDerived d) {
+__global__ __launch_bounds__(BS_THREADS) void beam_step_kernel(grx_beam_step_args a, BeamDerived d, PlanCtx pc,
+                                                               grx_row_plan* __restrict__ plan_out) {
     __shared__ int s_cnt[BS_MAXK];
     __shared__ int s_base[BS_MAXK + 1];
     __shared__ float s_runin[BS_MAXK];
@@ -466,6 +468,22 @@ __global__ __launch_bounds__(BS_THREADS) void beam_step_kernel(grx_beam_step_arg
         a.unsat[b] = (unsat_old && any) ? 1 : 0;
     }
     STAMP(14);
+
+    // ---- optionally plan the next processor call for the rows this group just produced
+    if (plan_out != nullptr) {
+        // the sequence rows were written by other threads of this workgroup (barrier above STAMP(13))
+        const int T_next = a.cur_len + 1;
+        if (pc.mode == GRX_MODE_COUNT) {
+            if (b == 0 && tid == 0) plan_count_bookkeeping(pc);
+            for (int k = tid; k < K; k += BS_THREADS)
+                plan_out[row0 + k] = plan_count_row(pc, a.run_seq_out + (row0 + k) * L, T_next, (int)(row0 + k));
+        } else {
+            for (int k = wave; k < K; k += BS_WAVES) {
+                const grx_row_plan pl = plan_fixed_row(pc, a.run_seq_out + (row0 + k) * L, T_next, lane);
+                if (lane == 0) plan_out[row0 + k] = pl;
+            }
+        }
+    }
 }
 
 extern "C" int grx_beam_step(const grx_beam_step_args* args, void* stream) {
@@ -503,7 +521,14 @@ extern "C" int grx_beam_step(const grx_beam_step_args* args, void* stream) {
     d.reg_keys = (a.K <= BS_PREFETCH && a.cmax <= BS_THREADS && a.n_keep <= GRX_WAVE) ? 1 : 0;
     d.tails_in_lds = (a.K <= BS_TAIL_K && a.cur_len + 1 - a.copy_from <= BS_TAIL_W &&
                       a.cur_len - a.prompt_len + 1 <= BS_TAIL_W) ? 1 : 0;
-    hipLaunchKernelGGL(beam_step_kernel, dim3(a.B), dim3(BS_THREADS), 0, (hipStream_t)stream, a, d);
+    PlanCtx pc;
+    memset(&pc, 0, sizeof(pc));
+    grx_row_plan* plan_out = nullptr;
+    if (a.plan_next != nullptr) {
+        const int rc = grx_plan_ctx_for_next_call(who, a.plan_next, a.B * a.K, &pc, &plan_out);
+        if (rc != GRX_OK) return rc;
+    }
+    hipLaunchKernelGGL(beam_step_kernel, dim3(a.B), dim3(BS_THREADS), 0, (hipStream_t)stream, a, d, pc, plan_out);
     GRX_CHECK_HIP(hipGetLastError());
     return GRX_OK;
 }
@@ -563,5 +588,14 @@ extern "C" int grx_beam_init(const grx_beam_init_args* args, void* stream) {
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(beam_init_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
     GRX_CHECK_HIP(hipGetLastError());
+    if (a.plan_next != nullptr) {  // the first processor call sees the prompts themselves
+        PlanCtx pc;
+        grx_row_plan* plan_out = nullptr;
+        int rc = grx_plan_ctx_for_next_call(who, a.plan_next, a.B * a.K, &pc, &plan_out);
+        if (rc != GRX_OK) return rc;
+        rc = grx_launch_plan_kernel(pc, a.input_ids, a.ids_stride, a.B * a.K, a.prompt_len, plan_out,
+                                    (hipStream_t)stream);
+        if (rc != GRX_OK) return rc;
+    }
     return GRX_OK;
 }

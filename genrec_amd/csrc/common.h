@@ -216,3 +216,68 @@ __device__ __forceinline__ int resolve_fixed_row(const TrieView& tv, const int64
     }
     return GRX_RES_NOMATCH;
 }
+
+// ------------------------------------------------------------ row plans ---
+// Plan of one row for the streaming kernel: the governing trie node (or a negative
+// GRX_RES_* code), its child range, and the node of the row's count == 0 window.
+struct grx_row_plan {
+    int32_t code;
+    int32_t off;
+    int32_t n;
+    int32_t code0;
+};
+
+// What a kernel needs to plan rows for a processor call (kernel argument, by value).
+struct PlanCtx {
+    grx_state_words* st;  // null in fixed-hint mode without a state
+    int mode;             // GRX_MODE_*
+    int slot;             // state slot the planned call owns (count mode)
+    int prefix_index;
+    int eos;
+    TrieView tv;
+    PrefixArg pfx;
+};
+
+// Count-based mode (logit_processor.py:38-44), one thread per row: the window is the
+// last prefix_index + count tokens, where count is the shared counter after the previous
+// call.  Rows whose last prefix_index tokens equal prefix_ids reset the shared counter
+// for themselves and every later row (logit_processor.py:39-40); the lowest such row is
+// min-reduced into first_match[slot], and every row also gets the node of its count == 0
+// window (code0) for the streaming kernel to pick.
+__device__ __forceinline__ grx_row_plan plan_count_row(const PlanCtx& c, const int64_t* __restrict__ row, int T, int r) {
+    const int count = state_count_after(*c.st, (c.slot + 2) % 3);
+    const int s0 = py_tail_start(c.prefix_index, T);
+    if (c.pfx.n >= 0) {
+        bool match = (T - s0) == c.pfx.n;
+        for (int i = 0; match && i < c.pfx.n; ++i) match = row[s0 + i] == c.pfx.ids[i];
+        if (match) atomicMin(&c.st->first_match[c.slot], r);
+    }
+    const int start = py_tail_start(c.prefix_index + count, T);
+    grx_row_plan pl;
+    pl.code = trie_walk(c.tv, row + start, T - start);
+    pl.off = pl.code >= 0 ? c.tv.off[pl.code] : 0;
+    pl.n = pl.code >= 0 ? c.tv.off[pl.code + 1] - pl.off : 0;
+    pl.code0 = (c.pfx.n >= 0 && start != s0) ? trie_walk(c.tv, row + s0, T - s0) : pl.code;
+    return pl;
+}
+
+// Once per planned count-based call: record the counter the call runs with and re-arm the
+// match word of the call after it.  No kernel of the planned call reads these two words.
+__device__ __forceinline__ void plan_count_bookkeeping(const PlanCtx& c) {
+    const int count = state_count_after(*c.st, (c.slot + 2) % 3);
+    c.st->count[c.slot] = count;
+    c.st->first_match[(c.slot + 1) % 3] = GRX_NO_MATCH;
+}
+
+// Fixed-hint mode (fixed_hint_logit_processor.py:43-61), one wave per row; every lane
+// returns the same plan.
+__device__ __forceinline__ grx_row_plan plan_fixed_row(const PlanCtx& c, const int64_t* __restrict__ row, int T,
+                                                       int lane) {
+    const int code = resolve_fixed_row(c.tv, row, T, c.pfx, c.eos, lane);
+    grx_row_plan pl;
+    pl.code = code;
+    pl.off = code >= 0 ? c.tv.off[code] : 0;
+    pl.n = code >= 0 ? c.tv.off[code + 1] - pl.off : (code == GRX_RES_EOS ? 1 : 0);
+    pl.code0 = code;
+    return pl;
+}

@@ -5,20 +5,20 @@
 
 PrefixArg grx_prefix_arg(const grx_constraint* con);
 
-// Plan of one row for the streaming kernel: the governing trie node (or a negative
-// GRX_RES_* code), its child range, and the node of the row's count == 0 window.
-struct grx_row_plan {
-    int32_t code;
-    int32_t off;
-    int32_t n;
-    int32_t code0;
-};
-
 // Open a processor call on `stream`: picks the state slot a count-based call owns,
 // advances the host-side call counter and enqueues the kernel that writes one
 // grx_row_plan per row (and, count-based, finds the rows that end in prefix_ids).
 int grx_plan_rows(const grx_trie* trie, grx_state* state, const grx_rows* rows, const grx_constraint* con,
                   grx_row_plan* plan, hipStream_t stream, int* slot_out);
+
+// Planning context for the processor call that will follow on `state` (its slot is the one the
+// next count-based call owns; the host-side call counter is left alone), and the plan buffer
+// inside a caller workspace.  Used by the kernels that plan ahead for a grx_plan_request.
+int grx_plan_ctx_for_next_call(const char* who, const grx_plan_request* req, int32_t n_rows, PlanCtx* ctx,
+                               grx_row_plan** plan);
+// Plan `R` rows of `T` tokens for the next call with the stand-alone planning kernel (no call counting).
+int grx_launch_plan_kernel(const PlanCtx& ctx, const int64_t* ids, int64_t ids_stride, int R, int T,
+                           grx_row_plan* plan, hipStream_t stream);
 
 int grx_check_step_args(const char* who, const grx_trie* trie, const grx_state* state, const grx_rows* rows,
                         const grx_constraint* con, const void* workspace, size_t workspace_bytes);

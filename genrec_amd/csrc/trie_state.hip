@@ -185,55 +185,21 @@ extern "C" int grx_state_read(grx_state* s, int32_t out[4], void* stream) {
 // ------------------------------------------------------------- row plans ---
 // Which trie node governs each row, worked out ahead of the streaming kernel so
 // that kernel starts streaming after a single 16-byte load per row.
-//
-// Count-based mode (logit_processor.py:38-44), one thread per row: the window is
-// the last prefix_index + count tokens, where count is the shared counter after
-// the previous call.  Rows whose last prefix_index tokens equal prefix_ids reset
-// the shared counter for themselves and every later row (logit_processor.py:39-40);
-// the lowest such row is min-reduced into first_match[slot], and every row also
-// gets the node of its count == 0 window (code0) for the streaming kernel to pick.
-__global__ void plan_count_rows_kernel(grx_state_words* st, int slot, TrieView tv, const int64_t* __restrict__ ids,
-                                       int64_t ids_stride, int R, int T, PrefixArg pfx, int prefix_index,
+__global__ void plan_count_rows_kernel(PlanCtx c, const int64_t* __restrict__ ids, int64_t ids_stride, int R, int T,
                                        grx_row_plan* __restrict__ plan) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= R) return;
-    const int prev = (slot + 2) % 3;
-    const int count = state_count_after(*st, prev);
-    if (r == 0) {  // bookkeeping for the next call; no kernel of this call reads these words
-        st->count[slot] = count;
-        st->first_match[(slot + 1) % 3] = GRX_NO_MATCH;
-    }
-    const int64_t* row = ids + (int64_t)r * ids_stride;
-    const int s0 = py_tail_start(prefix_index, T);
-    if (pfx.n >= 0) {
-        bool match = (T - s0) == pfx.n;
-        for (int i = 0; match && i < pfx.n; ++i) match = row[s0 + i] == pfx.ids[i];
-        if (match) atomicMin(&st->first_match[slot], r);
-    }
-    const int start = py_tail_start(prefix_index + count, T);
-    grx_row_plan pl;
-    pl.code = trie_walk(tv, row + start, T - start);
-    pl.off = pl.code >= 0 ? tv.off[pl.code] : 0;
-    pl.n = pl.code >= 0 ? tv.off[pl.code + 1] - pl.off : 0;
-    pl.code0 = (pfx.n >= 0 && start != s0) ? trie_walk(tv, row + s0, T - s0) : pl.code;
-    plan[r] = pl;
+    if (r == 0) plan_count_bookkeeping(c);
+    plan[r] = plan_count_row(c, ids + (int64_t)r * ids_stride, T, r);
 }
 
-// Fixed-hint mode (fixed_hint_logit_processor.py:43-61), one wave per row.
-__global__ void plan_fixed_rows_kernel(TrieView tv, const int64_t* __restrict__ ids, int64_t ids_stride, int R, int T,
-                                       PrefixArg pfx, int eos, grx_row_plan* __restrict__ plan) {
+__global__ void plan_fixed_rows_kernel(PlanCtx c, const int64_t* __restrict__ ids, int64_t ids_stride, int R, int T,
+                                       grx_row_plan* __restrict__ plan) {
     const int lane = threadIdx.x & (GRX_WAVE - 1);
     const int r = (blockIdx.x * blockDim.x + threadIdx.x) / GRX_WAVE;
     if (r >= R) return;
-    const int code = resolve_fixed_row(tv, ids + (int64_t)r * ids_stride, T, pfx, eos, lane);
-    if (lane == 0) {
-        grx_row_plan pl;
-        pl.code = code;
-        pl.off = code >= 0 ? tv.off[code] : 0;
-        pl.n = code >= 0 ? tv.off[code + 1] - pl.off : (code == GRX_RES_EOS ? 1 : 0);
-        pl.code0 = code;
-        plan[r] = pl;
-    }
+    const grx_row_plan pl = plan_fixed_row(c, ids + (int64_t)r * ids_stride, T, lane);
+    if (lane == 0) plan[r] = pl;
 }
 
 // Bookkeeping of a count-based call that has no rows to process.
@@ -277,31 +243,74 @@ PrefixArg grx_prefix_arg(const grx_constraint* con) {
     return pfx;
 }
 
-// Open a processor call on `stream`: in the count-based mode pick the state slot the
-// call owns and advance the host-side call counter; enqueue the row planning kernel.
+static PlanCtx make_plan_ctx(const grx_trie* trie, grx_state* state, const grx_constraint* con, int slot) {
+    PlanCtx c;
+    memset(&c, 0, sizeof(c));
+    c.st = state ? state->dev : nullptr;
+    c.mode = con->mode;
+    c.slot = slot;
+    c.prefix_index = con->prefix_index;
+    c.eos = con->eos_token_id;
+    c.tv = grx_trie_view(trie);
+    c.pfx = grx_prefix_arg(con);
+    return c;
+}
+
+int grx_launch_plan_kernel(const PlanCtx& ctx, const int64_t* ids, int64_t ids_stride, int R, int T,
+                           grx_row_plan* plan, hipStream_t stream) {
+    const int threads = 256;
+    if (R <= 0) return GRX_OK;
+    if (ctx.mode == GRX_MODE_COUNT) {
+        hipLaunchKernelGGL(plan_count_rows_kernel, dim3((R + threads - 1) / threads), dim3(threads), 0, stream, ctx, ids,
+                           ids_stride, R, T, plan);
+    } else {
+        const int64_t total = (int64_t)R * GRX_WAVE;
+        hipLaunchKernelGGL(plan_fixed_rows_kernel, dim3((unsigned)((total + threads - 1) / threads)), dim3(threads), 0,
+                           stream, ctx, ids, ids_stride, R, T, plan);
+    }
+    GRX_CHECK_HIP(hipGetLastError());
+    return GRX_OK;
+}
+
+// Open a processor call on `stream`: in the count-based mode pick the state slot the call owns
+// and advance the host-side call counter; enqueue the row planning kernel unless the rows
+// arrive planned (grx_rows.planned).
 int grx_plan_rows(const grx_trie* trie, grx_state* state, const grx_rows* rows, const grx_constraint* con,
                   grx_row_plan* plan, hipStream_t stream, int* slot_out) {
     *slot_out = 0;
-    const int threads = 256;
+    int slot = 0;
     if (con->mode == GRX_MODE_COUNT) {
-        const int slot = (int)(state->calls % 3u);
+        slot = (int)(state->calls % 3u);
         *slot_out = slot;
-        if (rows->R == 0) {
-            hipLaunchKernelGGL(state_bookkeeping_kernel, dim3(1), dim3(1), 0, stream, state->dev, slot);
-        } else {
-            hipLaunchKernelGGL(plan_count_rows_kernel, dim3((rows->R + threads - 1) / threads), dim3(threads), 0,
-                               stream, state->dev, slot, grx_trie_view(trie), rows->input_ids, rows->ids_stride,
-                               rows->R, rows->T, grx_prefix_arg(con), con->prefix_index, plan);
-        }
-        GRX_CHECK_HIP(hipGetLastError());
         state->calls += 1;
-    } else if (rows->R > 0) {
-        const int64_t total = (int64_t)rows->R * GRX_WAVE;
-        hipLaunchKernelGGL(plan_fixed_rows_kernel, dim3((unsigned)((total + threads - 1) / threads)), dim3(threads), 0,
-                           stream, grx_trie_view(trie), rows->input_ids, rows->ids_stride, rows->R, rows->T,
-                           grx_prefix_arg(con), con->eos_token_id, plan);
-        GRX_CHECK_HIP(hipGetLastError());
+        if (rows->R == 0) {
+            // a planned empty call cannot exist: whoever planned had no rows to attach the bookkeeping to
+            hipLaunchKernelGGL(state_bookkeeping_kernel, dim3(1), dim3(1), 0, stream, state->dev, slot);
+            GRX_CHECK_HIP(hipGetLastError());
+            return GRX_OK;
+        }
     }
+    if (rows->planned || rows->R == 0) return GRX_OK;
+    return grx_launch_plan_kernel(make_plan_ctx(trie, state, con, slot), rows->input_ids, rows->ids_stride, rows->R,
+                                  rows->T, plan, stream);
+}
+
+int grx_plan_ctx_for_next_call(const char* who, const grx_plan_request* req, int32_t n_rows, PlanCtx* ctx,
+                               grx_row_plan** plan) {
+    GRX_REQUIRE(req->trie && req->con, GRX_E_INVALID, "%s: plan request without trie / constraint", who);
+    GRX_REQUIRE(req->con->mode == GRX_MODE_COUNT || req->con->mode == GRX_MODE_FIXED_HINT, GRX_E_INVALID,
+                "%s: plan request with bad mode %d", who, req->con->mode);
+    GRX_REQUIRE(req->con->mode != GRX_MODE_COUNT || req->state != nullptr, GRX_E_INVALID,
+                "%s: planning a count-based call needs its grx_state", who);
+    GRX_REQUIRE(req->con->n_prefix <= GRX_MAX_PREFIX, GRX_E_UNSUPPORTED, "%s: prefix_ids longer than %d tokens", who,
+                GRX_MAX_PREFIX);
+    GRX_REQUIRE(req->workspace != nullptr && ((uintptr_t)req->workspace & 15u) == 0 &&
+                    req->workspace_bytes >= grx_workspace_bytes(n_rows),
+                GRX_E_WORKSPACE, "%s: plan request needs a 16-byte aligned workspace of %zu bytes", who,
+                grx_workspace_bytes(n_rows));
+    const int slot = req->con->mode == GRX_MODE_COUNT ? (int)(req->state->calls % 3u) : 0;
+    *ctx = make_plan_ctx(req->trie, req->state, req->con, slot);
+    *plan = reinterpret_cast<grx_row_plan*>(reinterpret_cast<char*>(req->workspace) + GRX_WS_PLAN_OFFSET);
     return GRX_OK;
 }
 

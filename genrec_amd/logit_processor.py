@@ -126,6 +126,8 @@ class _TrieConstrainedBase(LogitsProcessor):
         self._states: dict[int, _DeviceState] = {}
         self._workspaces: dict[int, torch.Tensor] = {}
         self._active: Optional[int] = None  # device index of the last call
+        self._call_seq = 0                  # processor calls made so far (host side)
+        self._planned: Optional[tuple] = None  # rows whose plans a beam kernel has already written
 
     # -- trie ---------------------------------------------------------------------
     @property
@@ -156,6 +158,40 @@ class _TrieConstrainedBase(LogitsProcessor):
             ws = torch.zeros(nbytes, dtype=torch.uint8, device=torch.device("cuda", index))
             self._workspaces[key] = ws
         return ws
+
+    # -- planning ahead (fused loop) -----------------------------------------------------
+    def plan_request(self, device, n_rows: int):
+        """A ``grx_plan_request`` for the kernel that produces the rows of the next call (beam
+        init / beam step), plus the objects that must outlive the launch."""
+        index = device.index if device.index is not None else torch.cuda.current_device()
+        with torch.cuda.device(index):
+            st = self._state(index)
+            ws = self._workspace(index, n_rows)
+        con = self._constraint()
+        req = _lib.GrxPlanRequest()
+        req.trie = self.trie.device_handle(device)
+        req.state = st.ptr
+        req.con = C.addressof(con)
+        req.workspace = ws.data_ptr()
+        req.workspace_bytes = ws.numel()
+        return req, (con, ws)
+
+    def note_planned(self, rows_view: torch.Tensor) -> None:
+        """The kernel given ``plan_request`` has planned exactly ``rows_view`` ([R, T] view of the
+        running sequences) for the next call; anything that touches the counter cancels it."""
+        self._planned = (rows_view.data_ptr(), rows_view.shape[0], rows_view.shape[1],
+                         rows_view.stride(0) if rows_view.shape[0] > 1 else None, self._call_seq)
+
+    def _take_planned(self, rows: _lib.GrxRows, input_ids: torch.Tensor) -> None:
+        token = self._planned
+        self._planned = None
+        self._call_seq += 1
+        if token is None:
+            return
+        ptr, R, T, stride, seq = token
+        if (ptr == input_ids.data_ptr() and R == rows.R and T == rows.T and seq == self._call_seq - 1
+                and (stride is None or stride == input_ids.stride(0))):
+            rows.planned = 1
 
     def _constraint(self) -> _lib.GrxConstraint:
         con = _lib.GrxConstraint()
@@ -235,6 +271,7 @@ class _TrieConstrainedBase(LogitsProcessor):
                 raise ValueError("out must be a [rows, vocab] tensor on the device of scores with unit column stride")
             if out.dtype not in (torch.float32, scores_keep.dtype):
                 raise ValueError("out must be float32 or have the dtype of scores")
+        self._take_planned(rows, ids_keep)
         with torch.cuda.device(index):
             st = self._state(index)
             ws = self._workspace(index, rows.R)
@@ -275,6 +312,7 @@ class _TrieConstrainedBase(LogitsProcessor):
         rows, ids_keep, scores_keep = self._rows(input_ids, scores)
         index = self._device_index(scores_keep)
         assert cand.rows == rows.R and cand.buf.device == scores_keep.device
+        self._take_planned(rows, ids_keep)
         with torch.cuda.device(index):
             st = self._state(index)
             ws = self._workspace(index, rows.R)
@@ -388,6 +426,7 @@ class ConstrainedLogitsProcessor(_TrieConstrainedBase):
 
     @count.setter
     def count(self, value: int) -> None:
+        self._planned = None  # plans made with the old counter are void
         self._count_host = int(value)
         for st in self._states.values():
             self._push_count(st, self._count_host)

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define GRX_ABI_VERSION 2
+#define GRX_ABI_VERSION 3
 
 #if defined(GRX_BUILDING)
 #define GRX_API __attribute__((visibility("default")))
@@ -112,6 +112,9 @@ typedef struct grx_rows {
     int64_t scores_stride;    /* elements                                           */
     int32_t V;
     int32_t dtype;            /* GRX_F32 / GRX_BF16 / GRX_F16                       */
+    int32_t planned;          /* 1: the row plans for exactly these rows are already in the
+                                 workspace (see grx_plan_request); 0: plan them now   */
+    int32_t reserved;
 } grx_rows;
 
 typedef struct grx_constraint {
@@ -199,6 +202,25 @@ GRX_API int grx_constrained_candidates(const grx_trie* trie, grx_state* state, c
 GRX_API int grx_timing_enable(int on);
 GRX_API int grx_timing_read(double* total_ms, int32_t* launches);
 
+/*
+ * Planning ahead (no counterpart in the reference; used by the fused loop).  The
+ * two calls above start with a small kernel that works out which trie node governs
+ * every row.  The kernel that PRODUCES those rows can do that work instead:
+ * grx_beam_step / grx_beam_init given a grx_plan_request write the plans of their
+ * output rows (the running sequences, cur_len + 1 resp. prompt_len tokens each)
+ * into `workspace`, and the next processor call on those rows passes
+ * grx_rows.planned = 1 with the same trie / state / constraint / workspace.
+ * Nothing may touch the state (grx_state_set_count, another processor call) in
+ * between; the caller is responsible for that.
+ */
+typedef struct grx_plan_request {
+    const grx_trie* trie;
+    grx_state* state;          /* required in GRX_MODE_COUNT                          */
+    const grx_constraint* con;
+    void* workspace;           /* at least grx_workspace_bytes(B * K) bytes           */
+    size_t workspace_bytes;
+} grx_plan_request;
+
 /* -------------------------------------------------------------- beam step --- */
 
 /*
@@ -244,6 +266,7 @@ typedef struct grx_beam_step_args {
     int32_t* topk_token;       /* [B, n_keep]                                       */
     uint8_t* topk_hit;         /* [B, n_keep] next_token_hits_stopping_criteria     */
     int32_t* next_parent;      /* [B*K] flat cache-reorder index (b*K + parent)     */
+    const grx_plan_request* plan_next; /* NULL, or: also plan the next processor call  */
 } grx_beam_step_args;
 
 GRX_API int grx_beam_step(const grx_beam_step_args* args, void* stream);
@@ -268,6 +291,7 @@ typedef struct grx_beam_init_args {
     int32_t* fin_bidx[2];
     uint8_t* fin_done[2];
     uint8_t* unsat;
+    const grx_plan_request* plan_next; /* NULL, or: also plan the first processor call */
 } grx_beam_init_args;
 
 GRX_API int grx_beam_init(const grx_beam_init_args* args, void* stream);

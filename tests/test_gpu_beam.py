@@ -292,6 +292,69 @@ def test_processors_drop_into_transformers_generate_on_the_gpu(kind):
     ours.check_errors()
 
 
+@pytest.mark.parametrize("kind", ["count", "count_none", "fixed"])
+def test_plans_written_by_the_beam_kernels_equal_the_planning_kernel(kind):
+    """Fused loop: beam init / beam step also write the row plans of the next processor call.
+    In lockstep with a second processor that plans for itself, the plan words in the two
+    workspaces and the candidates are identical at every step, over two generations."""
+    from genrec_amd.beam import BeamSearchState
+    from genrec_amd.fixed_hint_logit_processor import FixedHintConstrainedLogitsProcessor
+    from genrec_amd.logit_processor import ConstrainedLogitsProcessor
+    from genrec_amd.trie import FlatTrie, create_prefix_allowed_tokens_fn
+
+    dev = _dev()
+    data, meta = load_npz("beams.npz")
+    prefix, eos, pad, V = meta["prefix"], meta["eos"], meta["pad"], meta["V"]
+    trie = FlatTrie(data["trie_sequences"].tolist())
+    fn = create_prefix_allowed_tokens_fn(trie, prefix)
+    K, B, steps = 8, 5, 4
+
+    def make():
+        if kind == "fixed":
+            return FixedHintConstrainedLogitsProcessor(fn, K, 3, prefix, eos, sync_errors=False)
+        return ConstrainedLogitsProcessor(fn, K, 3, prefix if kind == "count" else None, eos, sync_errors=False)
+
+    ahead, alone = make(), make()
+    g = torch.Generator().manual_seed(9)
+    plan_off = 256 * 4 + 2048 * 8  # counters + partials come first in the workspace
+
+    def plans(proc, R):
+        ws = next(iter(proc._workspaces.values()))
+        return ws[plan_off : plan_off + 16 * R].view(torch.int32).view(R, 4).clone()
+
+    for generation in range(2):
+        prompts = torch.cat([torch.randint(20, 90, (B, 5), generator=g), torch.tensor([prefix] * B)], dim=1)
+        rows = prompts.repeat_interleave(K, dim=0).to(dev)
+        for p in (ahead, alone):
+            if hasattr(p, "reset"):
+                p.count = 0
+        st_a = BeamSearchState(rows, K, rows.shape[1] + steps + 1, eos, pad, 1.0, False, planner=ahead)
+        st_b = BeamSearchState(rows, K, rows.shape[1] + steps + 1, eos, pad, 1.0, False)
+        cand_a = Candidates(B * K, trie.max_fanout, dev)
+        cand_b = Candidates(B * K, trie.max_fanout, dev)
+        for t in range(steps):
+            logits = (torch.randn(B * K, V, generator=g) * 3).to(dev)
+            assert ahead._planned is not None
+            ahead.candidates_into(st_a.flat_running_sequences(), logits, cand_a)
+            alone.candidates_into(st_b.flat_running_sequences(), logits, cand_b)
+            pa, pb = plans(ahead, B * K), plans(alone, B * K)
+            used = pb[:, 0] >= 0
+            assert torch.equal(pa[:, 0], pb[:, 0]) and torch.equal(pa[:, 3], pb[:, 3]), f"step {t}: nodes differ"
+            assert torch.equal(pa[used], pb[used]), f"step {t}: child ranges differ"
+            assert torch.equal(cand_a.count, cand_b.count)
+            valid = torch.arange(cand_a.cmax, device=dev)[None, :] < cand_a.count[:, None]
+            assert torch.equal(cand_a.tokens[valid], cand_b.tokens[valid])
+            assert torch.equal(cand_a.logp[valid], cand_b.logp[valid])
+            st_a.step(cand_a, V, planner=ahead)
+            st_b.step(cand_b, V)
+            assert torch.equal(st_a.running_sequences, st_b.running_sequences)
+        ahead._planned = None  # the plans made by the last step are for rows nobody will process
+    if kind != "fixed":
+        assert ahead.count == alone.count
+    ahead.check_errors()
+    alone.check_errors()
+
+
 def test_beam_step_large_random_against_oracle():
     """Synthetic candidates at rollout scale (K=16 and K=50, fan-out up to 242): exact top-2K order."""
     from oracle.beam import RefBeamSearch
