@@ -478,7 +478,45 @@ __global__ __launch_bounds__(BS_THREADS) void beam_step_kernel(grx_beam_step_arg
             for (int k = tid; k < K; k += BS_THREADS)
                 plan_out[row0 + k] = plan_count_row(pc, a.run_seq_out + (row0 + k) * L, T_next, (int)(row0 + k));
         } else {
+            // Fixed-hint mode.  A new row is its parent's row plus one token, so its first valid prefix
+            // occurrence is the parent's whenever the parent's node continues with that token onto a
+            // node that has children: occurrences before the parent's stay invalid with one more token.
+            // Rows that end in EOS take the EOS rule; everything else (parent already finished, leaf
+            // reached without an EOS id) is rescanned the general way, one wave per row.
+            __shared__ int s_pcode[BS_MAXK];
+            __shared__ unsigned char s_rescan[BS_MAXK];
+            for (int k = tid; k < K; k += BS_THREADS) s_pcode[k] = plan_out[row0 + k].code;  // this call's plans
+            __syncthreads();
+            for (int k = tid; k < K; k += BS_THREADS) {
+                const int j = s_run_idx[k];
+                const int tokv = s_tok[j], pcode = s_pcode[s_parent[j]];
+                grx_row_plan pl;
+                pl.code = GRX_RES_EMPTY;
+                bool known = false;
+                if (pc.eos >= 0 && tokv == pc.eos) {
+                    pl.code = GRX_RES_EOS;
+                    pl.off = 0;
+                    pl.n = 1;
+                    known = true;
+                } else if (pcode >= 0) {
+                    const int child = trie_child(pc.tv, pcode, (int64_t)tokv);
+                    if (child >= 0) {
+                        const int lo = pc.tv.off[child], hi = pc.tv.off[child + 1];
+                        if (hi > lo) {
+                            pl.code = child;
+                            pl.off = lo;
+                            pl.n = hi - lo;
+                            known = true;
+                        }
+                    }
+                }
+                pl.code0 = pl.code;
+                s_rescan[k] = known ? 0 : 1;
+                if (known) plan_out[row0 + k] = pl;
+            }
+            __syncthreads();
             for (int k = wave; k < K; k += BS_WAVES) {
+                if (!s_rescan[k]) continue;
                 const grx_row_plan pl = plan_fixed_row(pc, a.run_seq_out + (row0 + k) * L, T_next, lane);
                 if (lane == 0) plan_out[row0 + k] = pl;
             }
