@@ -1,0 +1,121 @@
+"""Trie-constrained beam search for a Hugging Face causal LM with the fused decoding step.
+
+The reference decodes with ``model.generate(num_beams=K, logits_processor=[processor])``
+(evaluate.py:363-371, MIMIGenRec.py:79, hint_sft_trainer.py:355-356), i.e. transformers'
+``_beam_search``: every step it normalises the [B*K, V] logits, runs the processors, adds the
+running scores, takes a dense top-2K and re-orders the KV cache.  ``constrained_generate`` keeps
+the model side of that loop (forward pass, KV cache, attention mask, position ids) and replaces
+everything behind the logits by two kernels per step (masked log-softmax to compact candidates,
+beam step).  Outputs mirror ``generate(..., return_dict_in_generate=True)``: ``sequences``,
+``sequences_scores`` and ``beam_indices`` of the ``num_return_sequences`` best beams per prompt.
+
+It also prefills each prompt ONCE and repeats the cache for the K beams, where
+``generate()`` prefills K identical copies of every prompt (generation/utils.py
+``_expand_inputs_for_generation``).
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from .beam import BeamSearchState
+from .logit_processor import Candidates
+
+
+@dataclass
+class ConstrainedBeamOutput:
+    sequences: torch.Tensor         # [B * num_return_sequences, prompt_len + generated]
+    sequences_scores: torch.Tensor  # [B * num_return_sequences]
+    beam_indices: torch.Tensor      # [B * num_return_sequences, generated]
+    steps: int
+
+
+@torch.no_grad()
+def constrained_generate(
+    model,
+    input_ids: torch.Tensor,
+    processor,
+    num_beams: int,
+    max_new_tokens: int,
+    attention_mask: Optional[torch.Tensor] = None,
+    eos_token_id: Optional[int] = None,
+    pad_token_id: Optional[int] = None,
+    length_penalty: float = 1.0,
+    early_stopping=False,
+    num_return_sequences: Optional[int] = None,
+    max_steps: Optional[int] = None,
+    share_prefill: bool = True,
+) -> ConstrainedBeamOutput:
+    """``input_ids`` [B, T] (left-padded like the reference's batches) on the model's device.
+
+    ``processor`` is a genrec_amd processor (pass ``repetition_penalty=`` to it for what
+    ``generate(repetition_penalty=...)`` would do).  ``max_steps`` fixes the number of decoding
+    steps (a trie of L levels always takes L + 1) and avoids the per-step host check of HF's loop
+    condition.  ``share_prefill=False`` prefills all K copies like ``generate()`` does.
+    """
+    B, T = input_ids.shape
+    K = int(num_beams)
+    dev = input_ids.device
+    if attention_mask is None:
+        attention_mask = torch.ones_like(input_ids)
+    eos = eos_token_id if eos_token_id is not None else getattr(model.config, "eos_token_id", None)
+    pad = pad_token_id if pad_token_id is not None else getattr(model.config, "pad_token_id", None)
+    if isinstance(eos, (list, tuple)):
+        eos = eos[0]
+
+    if hasattr(processor, "reset"):
+        processor.reset()
+    rows = input_ids.repeat_interleave(K, dim=0)
+    state = BeamSearchState(rows, K, T + max_new_tokens, eos, pad, length_penalty, early_stopping,
+                            shared_prompt=True, planner=processor)
+    cand = Candidates(B * K, max(processor.trie.max_fanout, 1), dev)
+
+    # ---- prefill
+    # as prepare_inputs_for_generation builds them: running count of real tokens, 1 on padding
+    position_ids = (attention_mask.long().cumsum(-1) - 1).masked_fill(attention_mask == 0, 1)
+    if share_prefill:
+        out = model(input_ids=input_ids, attention_mask=attention_mask, position_ids=position_ids, use_cache=True,
+                    return_dict=True)
+        cache = out.past_key_values
+        cache.batch_repeat_interleave(K)
+        logits = out.logits[:, -1, :].repeat_interleave(K, dim=0)
+        mask = attention_mask.repeat_interleave(K, dim=0)
+    else:
+        mask = attention_mask.repeat_interleave(K, dim=0)
+        out = model(input_ids=rows, attention_mask=mask, position_ids=position_ids.repeat_interleave(K, dim=0),
+                    use_cache=True, return_dict=True)
+        cache = out.past_key_values
+        logits = out.logits[:, -1, :]
+    del out
+    next_pos = mask.long().sum(dim=1, keepdim=True)  # position of the first generated token
+
+    step = 0
+    while True:
+        flat = state.flat_running_sequences()
+        logits = logits.contiguous()
+        processor.candidates_into(flat, logits, cand)
+        res = state.step(cand, logits.shape[-1], planner=processor)
+        step += 1
+        if max_steps is not None:
+            if step >= max_steps:
+                break
+        elif not state.has_unfinished():
+            break
+        if step >= max_new_tokens:
+            break
+        # ---- model side of the next step: re-order the cache, feed the tokens just chosen
+        cache.reorder_cache(res.next_parent.long())
+        new_tokens = state.running_sequences.view(B * K, -1)[:, state.cur_len - 1 : state.cur_len]
+        mask = torch.cat([mask, torch.ones((B * K, 1), dtype=mask.dtype, device=dev)], dim=1)
+        out = model(input_ids=new_tokens, attention_mask=mask, position_ids=next_pos, past_key_values=cache,
+                    use_cache=True, return_dict=True)
+        next_pos = next_pos + 1
+        logits = out.logits[:, -1, :]
+        cache = out.past_key_values
+        del out
+    seqs, scores, bidx = state.finalize(num_return_sequences)
+    processor.check_errors()
+    return ConstrainedBeamOutput(seqs, scores, bidx, step)

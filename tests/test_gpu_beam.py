@@ -355,6 +355,67 @@ def test_plans_written_by_the_beam_kernels_equal_the_planning_kernel(kind):
     alone.check_errors()
 
 
+@pytest.mark.parametrize("kind,penalty", [("count", 1.0), ("fixed", 1.0), ("count", 1.1)])
+def test_constrained_generate_matches_transformers_generate(kind, penalty):
+    """constrained_generate (our loop around a HF model: shared prefill, cache re-ordering, attention
+    mask and position ids for left-padded prompts) against model.generate() with the same processor in
+    its LogitsProcessorList: same sequences and beam indices, scores within 1e-4, with and without a
+    repetition penalty, with the prefill shared across beams or repeated per beam."""
+    from transformers import LogitsProcessorList, Qwen2Config, Qwen2ForCausalLM
+
+    from genrec_amd.fixed_hint_logit_processor import FixedHintConstrainedLogitsProcessor
+    from genrec_amd.generate import constrained_generate
+    from genrec_amd.logit_processor import ConstrainedLogitsProcessor
+    from genrec_amd.trie import FlatTrie, create_prefix_allowed_tokens_fn
+
+    dev = _dev()
+    data, meta = load_npz("beams.npz")
+    prefix, eos, pad, V = meta["prefix"], meta["eos"], meta["pad"], meta["V"]
+    seqs = data["trie_sequences"].tolist()
+    fn = create_prefix_allowed_tokens_fn(FlatTrie(seqs), prefix)
+    K = 8
+    torch.manual_seed(11)
+    cfg = Qwen2Config(vocab_size=V, hidden_size=32, intermediate_size=64, num_hidden_layers=2,
+                      num_attention_heads=2, num_key_value_heads=2, max_position_embeddings=128,
+                      eos_token_id=eos, pad_token_id=pad, bos_token_id=None, tie_word_embeddings=False)
+    model = Qwen2ForCausalLM(cfg).eval()
+    with torch.no_grad():
+        for p in model.parameters():
+            p.mul_(6.0)
+    model = model.to(dev)
+
+    def make(**kw):
+        if kind == "count":
+            return ConstrainedLogitsProcessor(fn, K, 3, prefix, eos, **kw)
+        return FixedHintConstrainedLogitsProcessor(fn, K, 3, prefix, eos, **kw)
+
+    g = torch.Generator().manual_seed(21)
+    sid = sorted({t for s in seqs for t in s[len(prefix):-1]})
+    rows, lens = [], [9, 6, 11]
+    for n in lens:  # left-padded prompts of different lengths, with trie tokens in their history
+        body = torch.randint(20, 90, (n,), generator=g).tolist()
+        body[: n // 2] = [sid[int(i)] for i in torch.randint(0, len(sid), (n // 2,), generator=g)]
+        rows.append([pad] * (max(lens) - n) + body + prefix)
+    prompts = torch.tensor(rows, device=dev)
+    mask = (prompts != pad).long()
+    with torch.no_grad():
+        want = model.generate(prompts, attention_mask=mask, logits_processor=LogitsProcessorList([make()]),
+                              num_beams=K, num_return_sequences=K, max_new_tokens=8, do_sample=False,
+                              length_penalty=0.0, repetition_penalty=penalty, eos_token_id=eos, pad_token_id=pad,
+                              output_scores=True, return_dict_in_generate=True)
+    live = want.sequences_scores > LIVE
+    assert int(live.sum()) >= 12
+    for share in (True, False):
+        got = constrained_generate(model, prompts, make(repetition_penalty=penalty), K, 8, attention_mask=mask,
+                                   eos_token_id=eos, pad_token_id=pad, length_penalty=0.0, share_prefill=share)
+        assert got.steps == len(want.scores)
+        w = min(got.sequences.shape[1], want.sequences.shape[1])
+        assert torch.equal(got.sequences[:, :w][live], want.sequences[:, :w][live]), f"share_prefill={share}"
+        bw = min(got.beam_indices.shape[1], want.beam_indices.shape[1])
+        assert torch.equal(got.beam_indices[:, :bw][live].long(), want.beam_indices[:, :bw][live].long())
+        assert float((got.sequences_scores[live] - want.sequences_scores[live]).abs().max()) <= 1e-4
+
+
 def test_beam_step_large_random_against_oracle():
     """Synthetic candidates at rollout scale (K=16 and K=50, fan-out up to 242): exact top-2K order."""
     from oracle.beam import RefBeamSearch
