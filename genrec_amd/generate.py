@@ -73,12 +73,15 @@ def constrained_generate(
                             shared_prompt=True, planner=processor)
     cand = Candidates(B * K, max(processor.trie.max_fanout, 1), dev)
 
-    # ---- prefill
+    # ---- prefill (only the last position's logits are needed: the LM head is the widest matmul)
+    import inspect
+
+    last_only = {"logits_to_keep": 1} if "logits_to_keep" in inspect.signature(model.forward).parameters else {}
     # as prepare_inputs_for_generation builds them: running count of real tokens, 1 on padding
     position_ids = (attention_mask.long().cumsum(-1) - 1).masked_fill(attention_mask == 0, 1)
     if share_prefill:
         out = model(input_ids=input_ids, attention_mask=attention_mask, position_ids=position_ids, use_cache=True,
-                    return_dict=True)
+                    return_dict=True, **last_only)
         cache = out.past_key_values
         cache.batch_repeat_interleave(K)
         logits = out.logits[:, -1, :].repeat_interleave(K, dim=0)
@@ -86,7 +89,7 @@ def constrained_generate(
     else:
         mask = attention_mask.repeat_interleave(K, dim=0)
         out = model(input_ids=rows, attention_mask=mask, position_ids=position_ids.repeat_interleave(K, dim=0),
-                    use_cache=True, return_dict=True)
+                    use_cache=True, return_dict=True, **last_only)
         cache = out.past_key_values
         logits = out.logits[:, -1, :]
     del out
