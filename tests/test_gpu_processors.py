@@ -486,6 +486,48 @@ def test_empty_and_degenerate_batches_follow_the_reference():
         ours(torch.tensor([prefix]).to(dev), torch.zeros(1, 8, device=dev))
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("V", [2041, 2044, 2047])
+def test_aligned_rows_with_a_ragged_width(V, dtype):
+    """Row starts are 16-byte aligned (views into wider buffers) but the width is not a multiple of
+    the vector width: the vector stream covers the whole vectors, an element-wise tail the rest, for
+    the dense fill as well."""
+    from oracle.processors import DictTrie, RefConstrainedLogitsProcessor
+
+    from genrec_amd.logit_processor import ConstrainedLogitsProcessor
+    from genrec_amd.trie import FlatTrie, create_prefix_allowed_tokens_fn
+
+    data, meta, _, _ = _small_setup()
+    dev = _dev()
+    seqs = data["trie_sequences"].tolist()
+    assert max(t for s_ in seqs for t in s_) < V
+    fn = create_prefix_allowed_tokens_fn(FlatTrie(seqs), meta["prefix"])
+    K = meta["K"]
+    ids = torch.from_numpy(data["count_rl.ids.1"])
+    R = ids.shape[0]
+    torch.manual_seed(V)
+    wide = (torch.randn(R, 2048) * 5).to(dtype)
+    wide[:, -1] = 50.0  # a dominant value in the last (tail) column where it exists
+    ref = RefConstrainedLogitsProcessor(DictTrie(seqs).get, K, 3, meta["prefix"], meta["eos"])
+    ref.count = 1
+    want = ref(ids, wide[:, :V].float())
+    proc = ConstrainedLogitsProcessor(fn, K, 3, meta["prefix"], meta["eos"], sync_errors=True)
+    scores = wide.to(dev)[:, :V]
+    assert scores.stride(0) == 2048
+    backing = torch.full((R, 2048), 3.0, dtype=torch.float32, device=dev)
+    proc.count = 1
+    got = proc.call_into(ids.to(dev), scores, backing[:, :V]).cpu()
+    fin = torch.isfinite(want)
+    assert torch.equal(torch.isfinite(got), fin)
+    assert bool((backing[:, V:] == 3.0).all())
+    assert float((got[fin] - want[fin]).abs().max()) <= FP32_TOL * 2
+    proc.count = 1
+    cand = proc.candidates(ids.to(dev), scores)
+    valid = torch.arange(cand.cmax, device=dev)[None, :] < cand.count[:, None]
+    assert torch.equal(cand.count.cpu().long(), fin.sum(dim=1))
+    assert float((cand.logp[valid].cpu() - want[fin]).abs().max()) <= FP32_TOL * 2
+
+
 def test_strided_inputs_and_unnormalised_extremes():
     """Non-contiguous views, very peaked rows and rows containing -inf."""
     from oracle.processors import DictTrie, RefFixedHintConstrainedLogitsProcessor
