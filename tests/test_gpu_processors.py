@@ -352,6 +352,14 @@ def test_few_rows_are_split_across_workgroups_with_the_same_results(dtype):
             assert float(err.max()) <= 4e-6
         else:  # one bf16 rounding of the fp32 value: half an ulp = 2^-9 relative
             assert bool((err <= ref.abs() * 2.0 ** -8 + 1e-6).all())
+    # split rows whose width leaves an element tail behind the last whole vector (handled by the last part)
+    Vr = V - 3
+    ragged = big[:16, :Vr]
+    ragged[5, Vr - 1] = 70.0  # the row's maximum sits in the tail
+    exact_r = torch.logsumexp(ragged.double(), dim=-1)
+    proc.count = 2
+    got = proc.candidates(big_ids[:16], ragged)
+    assert float((got.logsumexp.double() - exact_r).abs().max()) <= FP32_TOL
 
 
 def test_fused_repetition_penalty_matches_the_transformers_chain():
