@@ -31,7 +31,13 @@ def gather_rows(t: torch.Tensor) -> torch.Tensor:
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return t
     t = t.contiguous()
-    out = torch.empty((dist.get_world_size() * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    shape = (dist.get_world_size() * t.shape[0],) + tuple(t.shape[1:])
+    if t.is_cuda and dist.get_backend() == "gloo":
+        # gloo gathers host tensors only (debugging / rehearsal set-ups); RCCL takes the device tensor as is
+        out = torch.empty(shape, dtype=t.dtype)
+        dist.all_gather_into_tensor(out, t.cpu())
+        return out.to(t.device)
+    out = torch.empty(shape, dtype=t.dtype, device=t.device)
     dist.all_gather_into_tensor(out, t)
     return out
 
