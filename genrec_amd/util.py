@@ -19,15 +19,17 @@ from .logit_processor import ConstrainedLogitsProcessor
 from .trie import build_trie_from_index, create_prefix_allowed_tokens_fn
 
 
+_RANK_VARIABLES = ("RANK", "LOCAL_RANK", "ACCELERATE_PROCESS_INDEX", "PROCESS_INDEX")
+
+
 def is_main_process() -> bool:
-    for key in ("RANK", "LOCAL_RANK", "ACCELERATE_PROCESS_INDEX", "PROCESS_INDEX"):
-        value = os.environ.get(key)
-        if value is None:
-            continue
+    """Rank 0 or no launcher at all: the first rank variable that parses as an integer decides
+    (same variables and precedence as the reference's util.py:24-33)."""
+    for raw in map(os.environ.get, _RANK_VARIABLES):
         try:
-            return int(value) == 0
-        except ValueError:
-            continue
+            return int(raw) == 0
+        except (TypeError, ValueError):  # unset or not a number: look at the next variable
+            pass
     return True
 
 
