@@ -141,22 +141,23 @@ def compute_metrics(test_data: list, topk_list: list = None, save_path: Optional
 
 
 def save_metrics(metrics: dict, save_path: str, valid_topk: list) -> None:
-    """metrics.json (4 decimals) + metrics.tsv next to it (reference: evaluate.py:182-202)."""
-    import pandas as pd
-
-    def r4(x):
+    """Write ``metrics.json`` (values rounded to 4 decimals, indent 2) and, next to it, a one-row
+    ``metrics.tsv`` whose row label is the result directory without its first path component --
+    the two files evaluate.py:182-202 leaves behind (there through pandas; the bytes are the same)."""
+    shown = {}
+    for name, value in metrics.items():
         try:
-            return round(float(x), 4)
-        except Exception:
-            return x
-
-    rounded = {k: r4(v) for k, v in metrics.items()}
-    os.makedirs(os.path.dirname(save_path) or ".", exist_ok=True)
+            shown[name] = round(float(value), 4)
+        except (TypeError, ValueError):
+            shown[name] = value
+    folder = os.path.dirname(save_path) or "."
+    os.makedirs(folder, exist_ok=True)
     with open(save_path, "w", encoding="utf-8") as f:
-        json.dump(rounded, f, indent=2, ensure_ascii=False)
-    columns = [f"HR@{k}" for k in valid_topk] + [f"NDCG@{k}" for k in valid_topk]
-    row_path = os.path.dirname(save_path) or "."
-    row_name = row_path.split("/", 1)[1] if "/" in row_path else row_path
-    df = pd.DataFrame([{c: rounded.get(c) for c in columns}], index=[row_name])
-    df.index.name = "path"
-    df.to_csv(os.path.splitext(save_path)[0] + ".tsv", sep="\t", encoding="utf-8")
+        json.dump(shown, f, indent=2, ensure_ascii=False)
+
+    columns = [f"{kind}@{k}" for kind in ("HR", "NDCG") for k in valid_topk]
+    label = folder.split("/", 1)[1] if "/" in folder else folder
+    cells = ["" if shown.get(c) is None else repr(shown[c]) for c in columns]
+    with open(os.path.splitext(save_path)[0] + ".tsv", "w", encoding="utf-8", newline="") as f:
+        f.write("\t".join(["path"] + columns) + "\n")
+        f.write("\t".join([label] + cells) + "\n")

@@ -253,3 +253,32 @@ def test_decode_beams_reproduces_batch_decode():
                      [tok.encode("<a_0>")[0], tok.encode("<b_4>")[0], tok.encode("<c_3>")[0], tok.eos_token_id]]])
     assert decode_beams(ids, table) == [["<a_1><b_2>", "<a_0><b_4><c_3>"]]
     assert decode_beams(ids, table)[0] == [tok.decode(r) for r in ids[0]]
+
+
+def test_saved_metric_files_have_the_layout_pandas_gives_the_reference(tmp_path):
+    """metrics.json / metrics.tsv as evaluate.py:182-202 writes them (pandas DataFrame.to_csv there)."""
+    import json as _json
+
+    import pandas as pd
+
+    from genrec_amd.metrics import save_metrics
+
+    metrics = {"HR@1": 0.123456, "HR@5": 0.5, "HR@10": 1.0, "NDCG@1": 0.123456, "NDCG@5": 0.33335, "NDCG@10": 2 / 3}
+    valid = [1, 5, 10]
+    for sub in ("runs/exp1/eval", "flat"):
+        path = tmp_path / sub / "metrics.json"
+        cwd = os.getcwd()
+        os.chdir(tmp_path)
+        try:
+            save_metrics(metrics, os.path.join(sub, "metrics.json"), valid)
+        finally:
+            os.chdir(cwd)
+        rounded = {k: round(float(v), 4) for k, v in metrics.items()}
+        assert _json.load(open(path)) == rounded
+        assert open(path).read() == _json.dumps(rounded, indent=2, ensure_ascii=False)
+        cols = [f"HR@{k}" for k in valid] + [f"NDCG@{k}" for k in valid]
+        row_name = sub.split("/", 1)[1] if "/" in sub else sub
+        df = pd.DataFrame([{c: rounded.get(c) for c in cols}], index=[row_name])
+        df.index.name = "path"
+        want = df.to_csv(sep="\t", encoding="utf-8")
+        assert open(tmp_path / sub / "metrics.tsv", newline="").read() == want
