@@ -122,3 +122,32 @@ def constrained_generate(
     seqs, scores, bidx = state.finalize(num_return_sequences)
     processor.check_errors()
     return ConstrainedBeamOutput(seqs, scores, bidx, step)
+
+
+def make_fused_generate(model, processor, num_beams: int = 50, max_completion_length: int = 128,
+                        length_penalty: float = 1.0, max_steps: Optional[int] = None):
+    """A ``generate(*args, **kwargs)`` to install on a model in place of the wrapper the reference
+    builds in ``_make_mimigenrec_generate`` (MIMIGenRec.py:9-81): the trainer hands over every prompt
+    ``num_beams`` times ([B * K, T] ``input_ids`` / ``attention_mask``), the wrapper keeps the first copy
+    of each group (MIMIGenRec.py:74-78), resets the processor (26-48, 57-59) and beam-searches with
+    ``num_return_sequences = num_beams`` (66-67), returning the [B * K, T + generated] token tensor that
+    ``model.generate`` returns without ``return_dict_in_generate``.  Here the search is the fused loop.
+
+    Sampling arguments (temperature, top_p, top_k) have no effect on beam search without sampling, which
+    is what every launcher of the reference uses; pass ``repetition_penalty`` to the processor."""
+    K = int(num_beams)
+
+    def generate(*args, **kwargs):
+        input_ids = kwargs.get("input_ids", args[0] if args else None)
+        if input_ids is None or input_ids.dim() != 2 or input_ids.shape[0] % K:
+            raise ValueError(f"generate() needs input_ids of shape [batch * {K}, T]")
+        attention_mask = kwargs.get("attention_mask")
+        bs, dim = input_ids.shape[0] // K, input_ids.shape[-1]
+        prompts = input_ids.view(bs, K, dim)[:, 0, :]
+        mask = None if attention_mask is None else attention_mask.view(bs, K, dim)[:, 0, :]
+        out = constrained_generate(model, prompts.contiguous(), processor, K, max_completion_length,
+                                   attention_mask=None if mask is None else mask.contiguous(),
+                                   length_penalty=length_penalty, num_return_sequences=K, max_steps=max_steps)
+        return out.sequences
+
+    return generate

@@ -414,6 +414,15 @@ def test_constrained_generate_matches_transformers_generate(kind, penalty):
         bw = min(got.beam_indices.shape[1], want.beam_indices.shape[1])
         assert torch.equal(got.beam_indices[:, :bw][live].long(), want.beam_indices[:, :bw][live].long())
         assert float((got.sequences_scores[live] - want.sequences_scores[live]).abs().max()) <= 1e-4
+    if kind == "count" and penalty == 1.0:
+        # the trainer-facing wrapper (MIMIGenRec.py:50-79): every prompt arrives K times, one token tensor comes back
+        from genrec_amd.generate import make_fused_generate
+
+        gen = make_fused_generate(model, make(), num_beams=K, max_completion_length=8, length_penalty=0.0)
+        seqs_out = gen(input_ids=prompts.repeat_interleave(K, dim=0), attention_mask=mask.repeat_interleave(K, dim=0))
+        w = min(seqs_out.shape[1], want.sequences.shape[1])
+        assert seqs_out.shape[0] == prompts.shape[0] * K
+        assert torch.equal(seqs_out[:, :w][live], want.sequences[:, :w][live])
 
 
 def test_beam_step_large_random_against_oracle():
