@@ -260,8 +260,8 @@ __global__ __launch_bounds__(MLS_THREADS) void masked_lsm_kernel(MlsArgs a) {
     const T* __restrict__ row = reinterpret_cast<const T*>(a.scores) + (int64_t)r * a.scores_stride;
     MSTAMP(0);
 
-    // The first batch of the stream is issued before anything else: the row
-    // resolution below runs on scalar loads, which do not queue behind it.
+    // The first batch of the stream is issued before anything else: the plan
+    // lookup below is a scalar load, which does not queue behind it.
     const int nvec = a.V / EPV;
     int v_lo = 0, v_hi = nvec;  // this workgroup's share of the row's vectors
     if (SPLIT) {
