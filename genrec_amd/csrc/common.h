@@ -80,6 +80,10 @@ struct grx_state {
     grx_state_words* dev;
     int device;
     uint32_t calls;          // count-based calls issued so far (host side, stream order)
+    // grx_state_set_count only notes the value here; the kernel that plans the next call receives
+    // it as an argument (no launch for a counter reset), and that call clears it.
+    bool count_pending;
+    int32_t pending_count;
 };
 
 #define GRX_NO_MATCH 0x7FFFFFFF
@@ -232,6 +236,8 @@ struct PlanCtx {
     grx_state_words* st;  // null in fixed-hint mode without a state
     int mode;             // GRX_MODE_*
     int slot;             // state slot the planned call owns (count mode)
+    int count_set;        // 1: the caller set the counter since the last call; it starts at count_value
+    int count_value;
     int prefix_index;
     int eos;
     TrieView tv;
@@ -244,8 +250,12 @@ struct PlanCtx {
 // for themselves and every later row (logit_processor.py:39-40); the lowest such row is
 // min-reduced into first_match[slot], and every row also gets the node of its count == 0
 // window (code0) for the streaming kernel to pick.
+__device__ __forceinline__ int plan_start_count(const PlanCtx& c) {
+    return c.count_set ? c.count_value : state_count_after(*c.st, (c.slot + 2) % 3);
+}
+
 __device__ __forceinline__ grx_row_plan plan_count_row(const PlanCtx& c, const int64_t* __restrict__ row, int T, int r) {
-    const int count = state_count_after(*c.st, (c.slot + 2) % 3);
+    const int count = plan_start_count(c);
     const int s0 = py_tail_start(c.prefix_index, T);
     if (c.pfx.n >= 0) {
         bool match = (T - s0) == c.pfx.n;
@@ -264,7 +274,7 @@ __device__ __forceinline__ grx_row_plan plan_count_row(const PlanCtx& c, const i
 // Once per planned count-based call: record the counter the call runs with and re-arm the
 // match word of the call after it.  No kernel of the planned call reads these two words.
 __device__ __forceinline__ void plan_count_bookkeeping(const PlanCtx& c) {
-    const int count = state_count_after(*c.st, (c.slot + 2) % 3);
+    const int count = plan_start_count(c);
     c.st->count[c.slot] = count;
     c.st->first_match[(c.slot + 1) % 3] = GRX_NO_MATCH;
 }

@@ -105,20 +105,15 @@ extern "C" int32_t grx_trie_max_fanout(const grx_trie* t) { return t ? t->max_fa
 extern "C" int32_t grx_trie_max_token(const grx_trie* t) { return t ? t->max_token : -1; }
 
 // ----------------------------------------------------------------- state ---
-// set_count: make the NEXT call see `count` (its previous slot then reads count - 1, no match).
-__global__ void state_set_kernel(grx_state_words* st, int set_count, int prev_slot, int32_t count, int clear_err) {
-    if (set_count) {
-        st->count[prev_slot] = count - 1;
-        st->first_match[prev_slot] = GRX_NO_MATCH;
-    }
-    if (clear_err) st->err = GRX_NO_ERR;
-}
+__global__ void state_clear_error_kernel(grx_state_words* st) { st->err = GRX_NO_ERR; }
 
 extern "C" int grx_state_create(grx_state** out) {
     GRX_REQUIRE(out != nullptr, GRX_E_INVALID, "grx_state_create: null pointer");
     grx_state* s = new grx_state();
     s->dev = nullptr;
     s->calls = 0;
+    s->count_pending = false;
+    s->pending_count = 0;
     hipError_t e = hipGetDevice(&s->device);
     if (e == hipSuccess) e = hipMalloc((void**)&s->dev, sizeof(grx_state_words));
     if (e == hipSuccess) {
@@ -152,15 +147,15 @@ static inline int prev_slot_of(const grx_state* s) { return (int)((s->calls + 2u
 
 extern "C" int grx_state_set_count(grx_state* s, int32_t count, void* stream) {
     GRX_REQUIRE(s != nullptr, GRX_E_INVALID, "grx_state_set_count: null state");
-    hipLaunchKernelGGL(state_set_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, s->dev, 1, prev_slot_of(s), count,
-                       0);
-    GRX_CHECK_HIP(hipGetLastError());
+    (void)stream;  // nothing is enqueued: the next call's planning kernel is handed the value
+    s->count_pending = true;
+    s->pending_count = count;
     return GRX_OK;
 }
 
 extern "C" int grx_state_clear_error(grx_state* s, void* stream) {
     GRX_REQUIRE(s != nullptr, GRX_E_INVALID, "grx_state_clear_error: null state");
-    hipLaunchKernelGGL(state_set_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, s->dev, 0, 0, 0, 1);
+    hipLaunchKernelGGL(state_clear_error_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, s->dev);
     GRX_CHECK_HIP(hipGetLastError());
     return GRX_OK;
 }
@@ -170,7 +165,7 @@ extern "C" int grx_state_read(grx_state* s, int32_t out[4], void* stream) {
     grx_state_words w;
     GRX_CHECK_HIP(hipMemcpyAsync(&w, s->dev, sizeof(w), hipMemcpyDeviceToHost, (hipStream_t)stream));
     GRX_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
-    out[0] = state_count_after(w, prev_slot_of(s));
+    out[0] = s->count_pending ? s->pending_count : state_count_after(w, prev_slot_of(s));
     if (w.err == GRX_NO_ERR) {
         out[1] = GRX_ROWERR_NONE;
         out[2] = -1;
@@ -203,9 +198,9 @@ __global__ void plan_fixed_rows_kernel(PlanCtx c, const int64_t* __restrict__ id
 }
 
 // Bookkeeping of a count-based call that has no rows to process.
-__global__ void state_bookkeeping_kernel(grx_state_words* st, int slot) {
+__global__ void state_bookkeeping_kernel(grx_state_words* st, int slot, int count_set, int count_value) {
     const int prev = (slot + 2) % 3, next = (slot + 1) % 3;
-    st->count[slot] = state_count_after(*st, prev);
+    st->count[slot] = count_set ? count_value : state_count_after(*st, prev);
     st->first_match[next] = GRX_NO_MATCH;
 }
 
@@ -249,6 +244,8 @@ static PlanCtx make_plan_ctx(const grx_trie* trie, grx_state* state, const grx_c
     c.st = state ? state->dev : nullptr;
     c.mode = con->mode;
     c.slot = slot;
+    c.count_set = (state && state->count_pending) ? 1 : 0;
+    c.count_value = state ? state->pending_count : 0;
     c.prefix_index = con->prefix_index;
     c.eos = con->eos_token_id;
     c.tv = grx_trie_view(trie);
@@ -283,16 +280,19 @@ int grx_plan_rows(const grx_trie* trie, grx_state* state, const grx_rows* rows, 
         slot = (int)(state->calls % 3u);
         *slot_out = slot;
         state->calls += 1;
-        if (rows->R == 0) {
-            // a planned empty call cannot exist: whoever planned had no rows to attach the bookkeeping to
-            hipLaunchKernelGGL(state_bookkeeping_kernel, dim3(1), dim3(1), 0, stream, state->dev, slot);
-            GRX_CHECK_HIP(hipGetLastError());
-            return GRX_OK;
-        }
+    }
+    // a counter set since the last call reaches this call's planning (done ahead or now) and ends here
+    const PlanCtx ctx = make_plan_ctx(trie, state, con, slot);
+    if (state) state->count_pending = false;
+    if (con->mode == GRX_MODE_COUNT && rows->R == 0) {
+        // a planned empty call cannot exist: whoever planned had no rows to attach the bookkeeping to
+        hipLaunchKernelGGL(state_bookkeeping_kernel, dim3(1), dim3(1), 0, stream, state->dev, slot, ctx.count_set,
+                           ctx.count_value);
+        GRX_CHECK_HIP(hipGetLastError());
+        return GRX_OK;
     }
     if (rows->planned || rows->R == 0) return GRX_OK;
-    return grx_launch_plan_kernel(make_plan_ctx(trie, state, con, slot), rows->input_ids, rows->ids_stride, rows->R,
-                                  rows->T, plan, stream);
+    return grx_launch_plan_kernel(ctx, rows->input_ids, rows->ids_stride, rows->R, rows->T, plan, stream);
 }
 
 int grx_plan_ctx_for_next_call(const char* who, const grx_plan_request* req, int32_t n_rows, PlanCtx* ctx,
