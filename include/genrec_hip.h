@@ -91,8 +91,10 @@ GRX_API int32_t grx_trie_max_token(const grx_trie* trie);
  * Python attributes: the shared step counter `count`
  * (logit_processor.py:24,27,40,48) and the first per-row failure of a call.
  * Keeping them on the device lets consecutive decode steps run without a
- * host round trip.  grx_state_create/destroy/read synchronise; the setters
- * are enqueued on `stream`.
+ * host round trip.  grx_state_create/destroy/read synchronise;
+ * grx_state_clear_error is enqueued on `stream`; grx_state_set_count enqueues
+ * nothing (the value is handed to the kernel that plans the next call, on that
+ * call's stream, and grx_state_read reports it at once).
  */
 GRX_API int grx_state_create(grx_state** out);
 GRX_API int grx_state_destroy(grx_state* st);
