@@ -309,6 +309,12 @@ def main() -> None:
         if world > 1:
             dist.barrier()
 
+    if world > 1:
+        # set the communicator's all-gather path up outside the timed region even when the warm-up is
+        # shorter than one rollout (the first collective of a process group connects its transports)
+        from genrec_amd.advantage import gather_rows
+
+        gather_rows(torch.zeros((args.batch * args.beams, 2), dtype=torch.float32, device=device))
     for _ in range(args.warmup):
         roll.step()
     roll.depth = wl["levels"]  # the timed region starts with a fresh generation

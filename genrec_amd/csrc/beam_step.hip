@@ -563,7 +563,7 @@ extern "C" int grx_beam_step(const grx_beam_step_args* args, void* stream) {
     memset(&pc, 0, sizeof(pc));
     grx_row_plan* plan_out = nullptr;
     if (a.plan_next != nullptr) {
-        const int rc = grx_plan_ctx_for_next_call(who, a.plan_next, a.B * a.K, &pc, &plan_out);
+        const int rc = grx_plan_ctx_for_next_call(who, a.plan_next, a.B * a.K, &pc, &plan_out, (hipStream_t)stream);
         if (rc != GRX_OK) return rc;
     }
     hipLaunchKernelGGL(beam_step_kernel, dim3(a.B), dim3(BS_THREADS), 0, (hipStream_t)stream, a, d, pc, plan_out);
@@ -629,7 +629,7 @@ extern "C" int grx_beam_init(const grx_beam_init_args* args, void* stream) {
     if (a.plan_next != nullptr) {  // the first processor call sees the prompts themselves
         PlanCtx pc;
         grx_row_plan* plan_out = nullptr;
-        int rc = grx_plan_ctx_for_next_call(who, a.plan_next, a.B * a.K, &pc, &plan_out);
+        int rc = grx_plan_ctx_for_next_call(who, a.plan_next, a.B * a.K, &pc, &plan_out, (hipStream_t)stream);
         if (rc != GRX_OK) return rc;
         rc = grx_launch_plan_kernel(pc, a.input_ids, a.ids_stride, a.B * a.K, a.prompt_len, plan_out,
                                     (hipStream_t)stream);

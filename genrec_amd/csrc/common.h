@@ -84,6 +84,10 @@ struct grx_state {
     // it as an argument (no launch for a counter reset), and that call clears it.
     bool count_pending;
     int32_t pending_count;
+    // A beam kernel has planned the next count-based call (and min-reduced row matches into that
+    // call's first_match word) but the call has not come yet.  If the plan is dropped -- the next
+    // call plans other rows itself, or another plan is made ahead first -- the word is re-armed.
+    bool ahead_open;
 };
 
 #define GRX_NO_MATCH 0x7FFFFFFF

@@ -15,7 +15,8 @@ int grx_plan_rows(const grx_trie* trie, grx_state* state, const grx_rows* rows, 
 // next count-based call owns; the host-side call counter is left alone), and the plan buffer
 // inside a caller workspace.  Used by the kernels that plan ahead for a grx_plan_request.
 int grx_plan_ctx_for_next_call(const char* who, const grx_plan_request* req, int32_t n_rows, PlanCtx* ctx,
-                               grx_row_plan** plan);
+                               grx_row_plan** plan,
+                               hipStream_t stream);
 // Plan `R` rows of `T` tokens for the next call with the stand-alone planning kernel (no call counting).
 int grx_launch_plan_kernel(const PlanCtx& ctx, const int64_t* ids, int64_t ids_stride, int R, int T,
                            grx_row_plan* plan, hipStream_t stream);

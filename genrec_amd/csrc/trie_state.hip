@@ -106,6 +106,8 @@ extern "C" int32_t grx_trie_max_token(const grx_trie* t) { return t ? t->max_tok
 
 // ----------------------------------------------------------------- state ---
 __global__ void state_clear_error_kernel(grx_state_words* st) { st->err = GRX_NO_ERR; }
+// Forget the row matches a dropped plan recorded for the call that owns `slot`.
+__global__ void state_rearm_kernel(grx_state_words* st, int slot) { st->first_match[slot] = GRX_NO_MATCH; }
 
 extern "C" int grx_state_create(grx_state** out) {
     GRX_REQUIRE(out != nullptr, GRX_E_INVALID, "grx_state_create: null pointer");
@@ -114,6 +116,7 @@ extern "C" int grx_state_create(grx_state** out) {
     s->calls = 0;
     s->count_pending = false;
     s->pending_count = 0;
+    s->ahead_open = false;
     hipError_t e = hipGetDevice(&s->device);
     if (e == hipSuccess) e = hipMalloc((void**)&s->dev, sizeof(grx_state_words));
     if (e == hipSuccess) {
@@ -284,6 +287,13 @@ int grx_plan_rows(const grx_trie* trie, grx_state* state, const grx_rows* rows, 
     // a counter set since the last call reaches this call's planning (done ahead or now) and ends here
     const PlanCtx ctx = make_plan_ctx(trie, state, con, slot);
     if (state) state->count_pending = false;
+    if (con->mode == GRX_MODE_COUNT) {
+        if (state->ahead_open && !rows->planned) {  // a plan made ahead for this slot is not the one that runs
+            hipLaunchKernelGGL(state_rearm_kernel, dim3(1), dim3(1), 0, stream, state->dev, slot);
+            GRX_CHECK_HIP(hipGetLastError());
+        }
+        state->ahead_open = false;
+    }
     if (con->mode == GRX_MODE_COUNT && rows->R == 0) {
         // a planned empty call cannot exist: whoever planned had no rows to attach the bookkeeping to
         hipLaunchKernelGGL(state_bookkeeping_kernel, dim3(1), dim3(1), 0, stream, state->dev, slot, ctx.count_set,
@@ -296,7 +306,7 @@ int grx_plan_rows(const grx_trie* trie, grx_state* state, const grx_rows* rows, 
 }
 
 int grx_plan_ctx_for_next_call(const char* who, const grx_plan_request* req, int32_t n_rows, PlanCtx* ctx,
-                               grx_row_plan** plan) {
+                               grx_row_plan** plan, hipStream_t stream) {
     GRX_REQUIRE(req->trie && req->con, GRX_E_INVALID, "%s: plan request without trie / constraint", who);
     GRX_REQUIRE(req->con->mode == GRX_MODE_COUNT || req->con->mode == GRX_MODE_FIXED_HINT, GRX_E_INVALID,
                 "%s: plan request with bad mode %d", who, req->con->mode);
@@ -309,6 +319,13 @@ int grx_plan_ctx_for_next_call(const char* who, const grx_plan_request* req, int
                 GRX_E_WORKSPACE, "%s: plan request needs a 16-byte aligned workspace of %zu bytes", who,
                 grx_workspace_bytes(n_rows));
     const int slot = req->con->mode == GRX_MODE_COUNT ? (int)(req->state->calls % 3u) : 0;
+    if (req->con->mode == GRX_MODE_COUNT) {
+        if (req->state->ahead_open) {  // the plan made ahead before this one was never used
+            hipLaunchKernelGGL(state_rearm_kernel, dim3(1), dim3(1), 0, stream, req->state->dev, slot);
+            GRX_CHECK_HIP(hipGetLastError());
+        }
+        req->state->ahead_open = true;
+    }
     *ctx = make_plan_ctx(req->trie, req->state, req->con, slot);
     *plan = reinterpret_cast<grx_row_plan*>(reinterpret_cast<char*>(req->workspace) + GRX_WS_PLAN_OFFSET);
     return GRX_OK;

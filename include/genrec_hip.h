@@ -212,8 +212,11 @@ GRX_API int grx_timing_read(double* total_ms, int32_t* launches);
  * output rows (the running sequences, cur_len + 1 resp. prompt_len tokens each)
  * into `workspace`, and the next processor call on those rows passes
  * grx_rows.planned = 1 with the same trie / state / constraint / workspace.
- * Nothing may touch the state (grx_state_set_count, another processor call) in
- * between; the caller is responsible for that.
+ * A plan made ahead may be dropped: a call that passes planned = 0 (other rows, or
+ * the counter was set in between) plans for itself and first erases what the
+ * dropped plan recorded in the state, and so does a second plan made ahead of the
+ * same call.  planned = 1 is only valid for exactly the rows that were planned,
+ * with no grx_state_set_count since.
  */
 typedef struct grx_plan_request {
     const grx_trie* trie;

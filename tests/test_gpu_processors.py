@@ -566,3 +566,30 @@ def test_strided_inputs_and_unnormalised_extremes():
     assert torch.equal(torch.isfinite(got), torch.isfinite(want))
     fin = torch.isfinite(want)
     assert (got - want)[fin].abs().max() <= 2e-5 * max(1.0, float(want[fin].abs().max()) / 10)
+
+
+def test_a_plan_made_ahead_and_then_dropped_leaves_no_trace():
+    """A beam kernel plans the next count-based call for prompt rows (which end in prefix_ids, so the
+    plan records a counter reset); the caller then processes other rows instead.  The call that
+    runs must not see the dropped plan's reset: results and counter as if it had never been made."""
+    from genrec_amd.beam import BeamSearchState
+
+    data, meta, trie, fn = _small_setup()
+    dev = _dev()
+    K, eos = meta["K"], meta["eos"]
+    case = "count_rl"
+    prompts = torch.from_numpy(data[f"{case}.ids.0"]).to(dev)
+    ids2 = torch.from_numpy(data[f"{case}.ids.2"]).to(dev)
+    scores2 = torch.from_numpy(data[f"{case}.scores.2"]).to(dev)
+    assert meta["cases"][case]["counts_after"][1] == 2  # the golden step 2 ran with count == 2
+
+    for drops in (1, 2):  # one dropped plan, and a dropped plan replaced by another dropped plan
+        proc = _make(case, fn, meta, sync_errors=True)
+        for _ in range(drops):
+            BeamSearchState(prompts, K, prompts.shape[1] + 8, eos, 0, 1.0, False, planner=proc)
+            assert proc._planned is not None
+        proc.count = 2
+        out = proc(ids2, scores2)
+        _assert_dense_close(out, data[f"{case}.out.2"], FP32_TOL)
+        assert proc.count == 3
+        proc.check_errors()
