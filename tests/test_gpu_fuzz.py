@@ -106,3 +106,84 @@ def test_random_tries_rows_and_counters(block):
             assert torch.equal(cand.tokens.cpu()[valid].long(), cols)
             assert float((cand.logp.cpu()[valid] - want[fin]).abs().max()) <= TOL
     assert outcomes["ok"] >= 10 and outcomes["AssertionError"] + outcomes["ValueError"] >= 5, outcomes
+
+
+LIVE = -1.0e8  # scores above this belong to real hypotheses; placeholder beams sit near -1e9
+
+
+def _random_beam_case(rng):
+    K = int(rng.choice([1, 2, 3, 5, 8, 16, 17, 33, 65, 100]))
+    B = int(rng.integers(1, 4))
+    V = int(rng.integers(40, 2500))
+    cmax = int(rng.integers(1, min(V - 2, 300 if K <= 17 else 24) + 1))
+    prompt_len = int(rng.choice([1, 4, 19]))
+    max_new = int(rng.integers(2, 7))
+    eos = int(rng.integers(0, 2)) if rng.random() < 0.75 else None
+    return dict(K=K, B=B, V=V, cmax=cmax, prompt_len=prompt_len, max_new=max_new, eos=eos,
+                shared=bool(rng.random() < 0.6),
+                early_stopping=[False, True, "never"][int(rng.integers(0, 3))],
+                length_penalty=float(rng.choice([0.0, 0.5, 1.0, 2.0])),
+                p_eos=float(rng.choice([0.0, 0.2, 0.6])), p_empty=float(rng.choice([0.0, 0.1])))
+
+
+@pytest.mark.parametrize("block", range(6))
+def test_random_beam_searches_against_the_oracle(block):
+    """Beam step fuzz: beam counts 1..100 (one wave, several waves, more beams than a wave), candidate
+    rows from empty to full, every early_stopping mode, length penalties, EOS or none, prompts shared
+    per group or not (sequence tails staged in LDS or copied from memory), run to max_length so the
+    forced stop is hit.  Every live slot of every step must equal the CPU restatement of the
+    transformers loop bit for bit."""
+    from oracle.beam import RefBeamSearch
+
+    from genrec_amd.beam import BeamSearchState
+    from genrec_amd.logit_processor import Candidates
+
+    dev = _dev()
+    rng = np.random.default_rng(7000 + block)
+    for _ in range(20):
+        c = _random_beam_case(rng)
+        K, B, V, cmax, P = c["K"], c["B"], c["V"], c["cmax"], c["prompt_len"]
+        R = B * K
+        if c["shared"]:
+            prompts = torch.from_numpy(rng.integers(2, V, size=(B, P))).repeat_interleave(K, dim=0)
+        else:
+            prompts = torch.from_numpy(rng.integers(2, V, size=(R, P)))
+        L = P + c["max_new"]
+        ref = RefBeamSearch(prompts, K, L, c["eos"], 0, c["length_penalty"], c["early_stopping"])
+        st = BeamSearchState(prompts.to(dev), K, L, c["eos"], 0, c["length_penalty"], c["early_stopping"],
+                             shared_prompt=c["shared"])
+        for step in range(c["max_new"]):
+            cnt = rng.integers(1, cmax + 1, size=R).astype(np.int32)
+            cnt[rng.random(R) < c["p_empty"]] = 0
+            tok = np.zeros((R, cmax), dtype=np.int32)
+            lp = np.zeros((R, cmax), dtype=np.float32)
+            dense = torch.full((R, V), float("-inf"))
+            for r in range(R):
+                n = int(cnt[r])
+                cols = np.sort(rng.choice(V - 2, size=n, replace=False) + 2)
+                if n and c["eos"] is not None and rng.random() < c["p_eos"]:
+                    cols[0] = c["eos"]  # eos < 2 <= every other column: still ascending
+                vals = (-rng.random(n) * 20).astype(np.float32)
+                tok[r, :n], lp[r, :n] = cols, vals
+                dense[r, torch.from_numpy(cols).long()] = torch.from_numpy(vals)
+            tr = ref.step(dense)
+            res = st.step(Candidates.from_parts(torch.from_numpy(cnt), torch.from_numpy(tok), torch.from_numpy(lp), dev), V)
+            tag = (c, step)
+            live = tr.topk_scores > LIVE
+            assert torch.equal(res.topk_scores.cpu()[live], tr.topk_scores[live]), tag
+            assert torch.equal(res.topk_token.cpu().long()[live], tr.topk_token[live]), tag
+            assert torch.equal(res.topk_parent.cpu().long()[live], tr.topk_parent[live]), tag
+            assert torch.equal(res.topk_hit.cpu().bool()[live], tr.topk_hit[live]), tag
+            run_live = ref.running_beam_scores > LIVE
+            assert torch.equal(st.running_beam_scores.cpu()[run_live], ref.running_beam_scores[run_live]), tag
+            assert torch.equal(st.running_sequences.cpu()[run_live], ref.running_sequences[run_live]), tag
+            assert torch.equal(st.run_bidx[st.cur].cpu()[run_live], ref.running_beam_indices[run_live]), tag
+            assert torch.equal(res.next_parent.cpu().view(B, K)[run_live], tr.next_parent.view(B, K)[run_live]), tag
+            fin_live = ref.beam_scores > LIVE
+            assert torch.equal(st.beam_scores.cpu()[fin_live], ref.beam_scores[fin_live]), tag
+            assert torch.equal(st.sequences.cpu()[fin_live], ref.sequences[fin_live]), tag
+            assert torch.equal(st.beam_indices.cpu()[fin_live], ref.beam_indices[fin_live]), tag
+            assert torch.equal(st.is_sent_finished.cpu()[fin_live], ref.is_sent_finished[fin_live]), tag
+            # the heuristic flag only depends on placeholder slots when the best running beam is one
+            decided = ref.running_beam_scores[:, 0] > LIVE
+            assert torch.equal(st.unsat.cpu().bool()[decided], ref.unsat[:, 0][decided]), tag
