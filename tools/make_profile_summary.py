@@ -17,7 +17,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-OURS = ("void masked_lsm", "beam_step", "plan_", "beam_init", "void sid_rew", "group_adv", "state_set", "fill_rows",
+OURS = ("void masked_lsm", "beam_step", "plan_", "beam_init", "void sid_rew", "group_adv", "state_", "fill_rows",
         "hit_ranks", "group_norm")
 
 
