@@ -123,6 +123,8 @@ class GrxBeamStepArgs(C.Structure):
         ("topk_hit", C.c_void_p),
         ("next_parent", C.c_void_p),
         ("plan_next", C.c_void_p),
+        ("cand_shared", C.c_int32),
+        ("reserved", C.c_int32),
     ]
 
 
@@ -144,6 +146,8 @@ class GrxBeamInitArgs(C.Structure):
         ("fin_done", C.c_void_p * 2),
         ("unsat", C.c_void_p),
         ("plan_next", C.c_void_p),
+        ("plan_one_per_group", C.c_int32),
+        ("reserved", C.c_int32),
     ]
 
 

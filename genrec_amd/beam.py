@@ -40,7 +40,7 @@ class BeamSearchState:
 
     def __init__(self, input_ids: torch.Tensor, num_beams: int, max_length: int, eos_token_id: Optional[int],
                  pad_token_id: Optional[int] = None, length_penalty: float = 1.0, early_stopping=False,
-                 shared_prompt: bool = True, planner=None):
+                 shared_prompt: bool = True, planner=None, first_step_shared: bool = False):
         _lib.require_cuda(input_ids, "input_ids")
         R, cur_len = input_ids.shape
         if R % num_beams:
@@ -77,15 +77,21 @@ class BeamSearchState:
         self.fin_done = pair((B, K), torch.uint8)
         self.unsat = torch.empty(B, dtype=torch.uint8, device=dev)
         self._step_out = None
-        self.reset(input_ids, planner)
+        self.reset(input_ids, planner, first_step_shared)
 
-    def reset(self, input_ids: torch.Tensor, planner=None) -> None:
+    def prompt_rows(self) -> torch.Tensor:
+        """[B, cur_len] view of the first beam of every group: the rows of a first processor call that
+        sees one row per group (``candidates_into(..., one_row_per_group=True)``)."""
+        return self.flat_running_sequences()[:: self.K]
+
+    def reset(self, input_ids: torch.Tensor, planner=None, first_step_shared: bool = False) -> None:
         """Start a new search from ``input_ids`` [B*K, prompt_len] (same shape as at
         construction) in the existing buffers: one kernel launch, no allocation.
 
         ``planner`` (a genrec_amd processor): also work out the trie node of every prompt row for
         the processor's next call, which then skips its own planning kernel.  The processor's
-        counter must already be what that call should see (reset it first)."""
+        counter must already be what that call should see (reset it first).  ``first_step_shared``:
+        that call will be made on ``prompt_rows()`` (one row per group), so only those are planned."""
         _lib.require_cuda(input_ids, "input_ids")
         if tuple(input_ids.shape) != (self.B * self.K, self.prompt_len):
             raise ValueError("reset() needs input_ids of the shape the state was built for")
@@ -109,8 +115,9 @@ class BeamSearchState:
         a.unsat = self.unsat.data_ptr()
         keep = None
         if planner is not None:
-            req, keep = planner.plan_request(self.device, self.B * self.K)
+            req, keep = planner.plan_request(self.device, self.B if first_step_shared else self.B * self.K)
             a.plan_next = C.addressof(req)
+            a.plan_one_per_group = 1 if first_step_shared else 0
         index = self.device.index if self.device.index is not None else torch.cuda.current_device()
         with torch.cuda.device(index):
             _lib.check(_lib.lib().grx_beam_init(C.byref(a), _lib.current_stream_ptr(self.device)))
@@ -119,7 +126,7 @@ class BeamSearchState:
         self.cur_len = self.prompt_len
         if planner is not None:
             # the plans describe the caller's prompt rows; the running-sequence view holds the same tokens
-            planner.note_planned(self.flat_running_sequences())
+            planner.note_planned(self.prompt_rows() if first_step_shared else self.flat_running_sequences())
 
     # -- views of the current state -------------------------------------------------
     @property
@@ -162,10 +169,15 @@ class BeamSearchState:
             )
         return self._step_out
 
-    def step(self, cand, vocab_size: int, planner=None) -> BeamStepResult:
+    def step(self, cand, vocab_size: int, planner=None, shared_rows: bool = False) -> BeamStepResult:
         """Advance by one token from the processor's compact candidates (a ``Candidates`` buffer).
         ``planner`` (the processor): the kernel also plans the processor's next call on the new
-        running sequences, so that call starts streaming at once."""
+        running sequences, so that call starts streaming at once.
+
+        ``shared_rows``: ``cand`` holds ONE row per group which all K beams extend from.  Valid
+        whenever the K rows of every group are equal, i.e. at the first step of a search whose beams
+        are copies of one prompt: the results are those of K equal candidate rows, and the
+        processor call that made ``cand`` read 1/K of the logits."""
         a = _lib.GrxBeamStepArgs()
         i, o = self.cur, 1 - self.cur
         out = self._outputs()
@@ -176,8 +188,9 @@ class BeamSearchState:
         a.eos_token_id = -1 if self.eos is None else int(self.eos)
         a.early_stopping = 1 if self.early_stopping is True else (2 if self.early_stopping == "never" else 0)
         a.length_penalty = self.length_penalty
-        assert cand.rows == self.B * self.K
+        assert cand.rows == (self.B if shared_rows else self.B * self.K)
         a.cand, a.cand_stride = cand.buf.data_ptr(), cand.stride
+        a.cand_shared = 1 if shared_rows else 0
         a.run_seq_in, a.run_seq_out = self.run_seq[i].data_ptr(), self.run_seq[o].data_ptr()
         a.run_score_in, a.run_score_out = self.run_score[i].data_ptr(), self.run_score[o].data_ptr()
         a.run_bidx_in, a.run_bidx_out = self.run_bidx[i].data_ptr(), self.run_bidx[o].data_ptr()

@@ -93,16 +93,18 @@ __global__ __launch_bounds__(BS_THREADS) void beam_step_kernel(grx_beam_step_arg
     // ---- phase A: every global read the step needs is issued before the first wait.
     // Thread t prefetches column t of the first BS_PREFETCH beams (coalesced rows).
     grx_cand pre[BS_PREFETCH];
-    const grx_cand* __restrict__ g_cand = a.cand + row0 * a.cand_stride;
+    // candidate row of beam k: g_cand + k * bstride (every beam reads the group's one row when they are shared)
+    const int64_t bstride = a.cand_shared ? 0 : a.cand_stride;
+    const grx_cand* __restrict__ g_cand = a.cand + (a.cand_shared ? (int64_t)b : row0) * a.cand_stride;
     if (d.reg_keys) {
 #pragma unroll
         for (int u = 0; u < BS_PREFETCH; ++u) {
             // entries past a beam's count hold stale values; they are masked below
-            pre[u] = g_cand[(u < K && tid < cmax) ? (int64_t)u * a.cand_stride + 1 + tid : 0];
+            pre[u] = g_cand[(u < K && tid < cmax) ? (int64_t)u * bstride + 1 + tid : 0];
         }
     }
     for (int k = tid; k < K; k += BS_THREADS) {
-        s_cnt[k] = g_cand[(int64_t)k * a.cand_stride].x;
+        s_cnt[k] = g_cand[(int64_t)k * bstride].x;
         s_runin[k] = a.run_score_in[row0 + k];
         s_fdone_in[k] = a.fin_done_in[row0 + k];
         s_merged[k] = a.fin_score_in[row0 + k];
@@ -134,7 +136,7 @@ __global__ __launch_bounds__(BS_THREADS) void beam_step_kernel(grx_beam_step_arg
     };
     auto key_of = [&](int c) -> unsigned long long {  // flat slot c = beam * cmax + position
         const int k = c / cmax, i = c - k * cmax;
-        const grx_cand e = g_cand[(int64_t)k * a.cand_stride + 1 + i];
+        const grx_cand e = g_cand[(int64_t)k * bstride + 1 + i];
         return key_at(k, i, __int_as_float(e.y), e.x);
     };
     auto emit = [&](int j, unsigned long long key) {
@@ -223,7 +225,7 @@ __global__ __launch_bounds__(BS_THREADS) void beam_step_kernel(grx_beam_step_arg
                 const int mid = (lo + hi) >> 1;
                 if (s_base[mid] <= c) lo = mid; else hi = mid;
             }
-            const grx_cand e = g_cand[(int64_t)lo * a.cand_stride + 1 + (c - s_base[lo])];
+            const grx_cand e = g_cand[(int64_t)lo * bstride + 1 + (c - s_base[lo])];
             return make_key(__int_as_float(e.y) + s_runin[lo], (uint32_t)lo, (uint32_t)e.x);
         };
         unsigned long long tmax = 0;
@@ -539,6 +541,7 @@ extern "C" int grx_beam_step(const grx_beam_step_args* args, void* stream) {
     GRX_REQUIRE(a.copy_from >= 0 && a.copy_from <= a.cur_len, GRX_E_INVALID, "%s: bad copy_from", who);
     GRX_REQUIRE(a.early_stopping >= 0 && a.early_stopping <= 2, GRX_E_INVALID, "%s: bad early_stopping", who);
     GRX_REQUIRE(a.cand_stride >= (int64_t)a.cmax + 1, GRX_E_INVALID, "%s: cand_stride smaller than cmax + 1", who);
+    GRX_REQUIRE(a.cand_shared == 0 || a.cand_shared == 1, GRX_E_INVALID, "%s: cand_shared must be 0 or 1", who);
     if (a.B == 0) return GRX_OK;
     GRX_REQUIRE(a.cand && a.run_seq_in && a.run_seq_out && a.run_score_in &&
                     a.run_score_out && a.run_bidx_in && a.run_bidx_out && a.fin_seq_in && a.fin_seq_out &&
@@ -629,9 +632,11 @@ extern "C" int grx_beam_init(const grx_beam_init_args* args, void* stream) {
     if (a.plan_next != nullptr) {  // the first processor call sees the prompts themselves
         PlanCtx pc;
         grx_row_plan* plan_out = nullptr;
-        int rc = grx_plan_ctx_for_next_call(who, a.plan_next, a.B * a.K, &pc, &plan_out, (hipStream_t)stream);
+        const int per = a.plan_one_per_group ? a.K : 1;  // plan every K-th row only
+        const int n_rows = a.B * a.K / per;
+        int rc = grx_plan_ctx_for_next_call(who, a.plan_next, n_rows, &pc, &plan_out, (hipStream_t)stream);
         if (rc != GRX_OK) return rc;
-        rc = grx_launch_plan_kernel(pc, a.input_ids, a.ids_stride, a.B * a.K, a.prompt_len, plan_out,
+        rc = grx_launch_plan_kernel(pc, a.input_ids, a.ids_stride * per, n_rows, a.prompt_len, plan_out,
                                     (hipStream_t)stream);
         if (rc != GRX_OK) return rc;
     }

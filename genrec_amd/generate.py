@@ -69,9 +69,12 @@ def constrained_generate(
     if hasattr(processor, "reset"):
         processor.reset()
     rows = input_ids.repeat_interleave(K, dim=0)
+    # With a shared prefill the K beams of a group start from one logit row: the first processor call
+    # reads B rows instead of B * K identical ones and the first beam step extends all beams from it.
     state = BeamSearchState(rows, K, T + max_new_tokens, eos, pad, length_penalty, early_stopping,
-                            shared_prompt=True, planner=processor)
-    cand = Candidates(B * K, max(processor.trie.max_fanout, 1), dev)
+                            shared_prompt=True, planner=processor, first_step_shared=share_prefill)
+    cmax = max(processor.trie.max_fanout, 1)
+    cand = Candidates(B * K, cmax, dev)
 
     # ---- prefill (only the last position's logits are needed: the LM head is the widest matmul)
     import inspect
@@ -84,7 +87,7 @@ def constrained_generate(
                     return_dict=True, **last_only)
         cache = out.past_key_values
         cache.batch_repeat_interleave(K)
-        logits = out.logits[:, -1, :].repeat_interleave(K, dim=0)
+        logits = out.logits[:, -1, :]  # [B, V]: one row per group
         mask = attention_mask.repeat_interleave(K, dim=0)
     else:
         mask = attention_mask.repeat_interleave(K, dim=0)
@@ -97,10 +100,14 @@ def constrained_generate(
 
     step = 0
     while True:
-        flat = state.flat_running_sequences()
         logits = logits.contiguous()
-        processor.candidates_into(flat, logits, cand)
-        res = state.step(cand, logits.shape[-1], planner=processor)
+        if step == 0 and share_prefill:
+            first = Candidates(B, cmax, dev)
+            processor.candidates_into(state.prompt_rows(), logits, first, one_row_per_group=True)
+            res = state.step(first, logits.shape[-1], planner=processor, shared_rows=True)
+        else:
+            processor.candidates_into(state.flat_running_sequences(), logits, cand)
+            res = state.step(cand, logits.shape[-1], planner=processor)
         step += 1
         if max_steps is not None:
             if step >= max_steps:

@@ -211,13 +211,14 @@ class _TrieConstrainedBase(LogitsProcessor):
         con.penalty_skip = self.prompt_ignore_length
         return con
 
-    def _rows(self, input_ids: torch.Tensor, scores: torch.Tensor) -> tuple[_lib.GrxRows, torch.Tensor, torch.Tensor]:
+    def _rows(self, input_ids: torch.Tensor, scores: torch.Tensor, whole_groups: bool = True
+              ) -> tuple[_lib.GrxRows, torch.Tensor, torch.Tensor]:
         assert input_ids.dim() == 2, "input_ids must be a 2D tensor"
         _lib.require_cuda(scores, "scores")
         _lib.require_cuda(input_ids, "input_ids")
         if scores.dim() != 2 or scores.shape[0] != input_ids.shape[0]:
             raise ValueError(f"scores must be [rows, vocab] with rows == {input_ids.shape[0]}; got {tuple(scores.shape)}")
-        if input_ids.shape[0] % self._num_beams != 0:
+        if whole_groups and input_ids.shape[0] % self._num_beams != 0:
             # the reference fails on view(-1, num_beams, seq_len) (logit_processor.py:36)
             raise RuntimeError(
                 f"shape '[-1, {self._num_beams}, {input_ids.shape[1]}]' is invalid for input of size {input_ids.numel()}"
@@ -307,9 +308,14 @@ class _TrieConstrainedBase(LogitsProcessor):
         self.candidates_into(input_ids, scores, cand)
         return cand
 
-    def candidates_into(self, input_ids, scores, cand: "Candidates") -> None:
-        """``candidates`` writing into a caller-owned buffer (no allocation per step)."""
-        rows, ids_keep, scores_keep = self._rows(input_ids, scores)
+    def candidates_into(self, input_ids, scores, cand: "Candidates", one_row_per_group: bool = False) -> None:
+        """``candidates`` writing into a caller-owned buffer (no allocation per step).
+
+        ``one_row_per_group``: the rows are prompts, one per beam group, instead of ``num_beams``
+        identical copies of each (the first step of a search: the copies would give identical
+        results, see ``BeamSearchState.step(..., shared_rows=True)``).  The shared counter moves
+        exactly as for the full batch."""
+        rows, ids_keep, scores_keep = self._rows(input_ids, scores, whole_groups=not one_row_per_group)
         index = self._device_index(scores_keep)
         assert cand.rows == rows.R and cand.buf.device == scores_keep.device
         self._take_planned(rows, ids_keep)

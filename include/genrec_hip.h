@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define GRX_ABI_VERSION 3
+#define GRX_ABI_VERSION 4
 
 #if defined(GRX_BUILDING)
 #define GRX_API __attribute__((visibility("default")))
@@ -272,6 +272,13 @@ typedef struct grx_beam_step_args {
     uint8_t* topk_hit;         /* [B, n_keep] next_token_hits_stopping_criteria     */
     int32_t* next_parent;      /* [B*K] flat cache-reorder index (b*K + parent)     */
     const grx_plan_request* plan_next; /* NULL, or: also plan the next processor call  */
+    int32_t cand_shared;       /* 1: cand is [B, cand_stride], ONE candidate row per group
+                                  that all K beams extend from.  For the first step of a
+                                  search whose K beams are copies of one prompt (what
+                                  generate() builds in _expand_inputs_for_generation): the
+                                  K logit rows are identical, so the processor call needs
+                                  to see only one of them.  Same results as K equal rows. */
+    int32_t reserved;
 } grx_beam_step_args;
 
 GRX_API int grx_beam_step(const grx_beam_step_args* args, void* stream);
@@ -297,6 +304,10 @@ typedef struct grx_beam_init_args {
     uint8_t* fin_done[2];
     uint8_t* unsat;
     const grx_plan_request* plan_next; /* NULL, or: also plan the first processor call */
+    int32_t plan_one_per_group; /* with plan_next: that call will see one row per group (rows
+                                   0, K, 2K, ... of input_ids; see grx_beam_step_args.cand_shared),
+                                   so B rows are planned instead of B * K */
+    int32_t reserved;
 } grx_beam_init_args;
 
 GRX_API int grx_beam_init(const grx_beam_init_args* args, void* stream);

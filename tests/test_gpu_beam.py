@@ -485,3 +485,69 @@ def test_tie_order_is_canonical():
     res = st.step(Candidates.from_parts(cnt, tok, lp, dev), V)
     assert res.topk_parent.cpu().tolist() == [[0, 0, 0, 1, 1, 1, 2, 2]]
     assert res.topk_token.cpu().tolist() == [[10, 20, 30, 10, 20, 30, 10, 20]]
+
+
+@pytest.mark.parametrize("kind", ["count", "count_none", "fixed"])
+def test_first_step_from_one_row_per_group_equals_k_copies(kind):
+    """The first step of a search whose K beams are copies of one prompt: a processor call on one row
+    per group + a beam step with shared candidate rows gives, bit for bit and in every slot, what K
+    identical logit rows give -- including the counter, over two generations (the second relies on
+    the reference's own mid-call reset when prefix_ids is given)."""
+    from genrec_amd.beam import BeamSearchState
+    from genrec_amd.fixed_hint_logit_processor import FixedHintConstrainedLogitsProcessor
+    from genrec_amd.logit_processor import ConstrainedLogitsProcessor
+    from genrec_amd.trie import FlatTrie, create_prefix_allowed_tokens_fn
+
+    dev = _dev()
+    data, meta = load_npz("beams.npz")
+    prefix, eos, pad, V = meta["prefix"], meta["eos"], meta["pad"], meta["V"]
+    trie = FlatTrie(data["trie_sequences"].tolist())
+    fn = create_prefix_allowed_tokens_fn(trie, prefix)
+    K, B, steps = 8, 5, 3
+
+    def make():
+        if kind == "fixed":
+            return FixedHintConstrainedLogitsProcessor(fn, K, 3, prefix, eos, sync_errors=False)
+        return ConstrainedLogitsProcessor(fn, K, 3, prefix if kind == "count" else None, eos, sync_errors=False)
+
+    one, full = make(), make()
+    g = torch.Generator().manual_seed(21)
+    for generation in range(2):
+        prompts = torch.cat([torch.randint(20, 90, (B, 5), generator=g), torch.tensor([prefix] * B)], dim=1)
+        rows = prompts.repeat_interleave(K, dim=0).to(dev)
+        for p in (one, full):
+            if hasattr(p, "reset") and (kind != "count" or generation == 0):
+                p.count = 0
+        L = rows.shape[1] + steps + 1
+        st_one = BeamSearchState(rows, K, L, eos, pad, 1.0, False, planner=one, first_step_shared=True)
+        st_full = BeamSearchState(rows, K, L, eos, pad, 1.0, False, planner=full)
+        assert one._planned is not None and one._planned[1] == B  # B rows were planned, not B * K
+        first = Candidates(B, trie.max_fanout, dev)
+        cand_one = Candidates(B * K, trie.max_fanout, dev)
+        cand_full = Candidates(B * K, trie.max_fanout, dev)
+        for t in range(steps):
+            if t == 0:
+                logits_b = (torch.randn(B, V, generator=g) * 3).to(dev)
+                one.candidates_into(st_one.prompt_rows(), logits_b, first, one_row_per_group=True)
+                full.candidates_into(st_full.flat_running_sequences(), logits_b.repeat_interleave(K, dim=0), cand_full)
+                assert torch.equal(first.buf, cand_full.buf[::K])
+                res_one = st_one.step(first, V, planner=one, shared_rows=True)
+            else:
+                logits = (torch.randn(B * K, V, generator=g) * 3).to(dev)
+                one.candidates_into(st_one.flat_running_sequences(), logits, cand_one)
+                full.candidates_into(st_full.flat_running_sequences(), logits, cand_full)
+                assert torch.equal(cand_one.count, cand_full.count)
+                res_one = st_one.step(cand_one, V, planner=one)
+            res_full = st_full.step(cand_full, V, planner=full)
+            for name in ("topk_scores", "topk_parent", "topk_token", "topk_hit", "next_parent"):
+                assert torch.equal(getattr(res_one, name), getattr(res_full, name)), (generation, t, name)
+            assert torch.equal(st_one.running_sequences, st_full.running_sequences)
+            assert torch.equal(st_one.running_beam_scores, st_full.running_beam_scores)
+            assert torch.equal(st_one.sequences, st_full.sequences)
+            assert torch.equal(st_one.beam_scores, st_full.beam_scores)
+        for p in (one, full):
+            p._planned = None
+    if kind != "fixed":
+        assert one.count == full.count
+    one.check_errors()
+    full.check_errors()
