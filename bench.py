@@ -275,6 +275,10 @@ def main() -> None:
     ap.add_argument("--no-plan-ahead", action="store_true",
                     help="let every processor call run its own row planning kernel (as under the plain HF loop)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="leave the per-launch HIP events out")
+    ap.add_argument("--time-every", type=int, default=4,
+                    help="attach HIP events to every n-th launch of the streaming kernel in the timed region (an "
+                         "event pair costs ~5 us of stream time; keep n coprime with the number of decode depths so "
+                         "every depth is sampled equally)")
     args = ap.parse_args()
 
     import torch
@@ -321,7 +325,7 @@ def main() -> None:
     torch.cuda.synchronize()
     barrier()
     lib = _lib.lib()
-    lib.grx_timing_enable(0 if args.no_kernel_timing else 1)
+    lib.grx_timing_enable(0 if args.no_kernel_timing else max(1, args.time_every))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -384,6 +388,7 @@ def main() -> None:
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "kernel_ms": kernel_ms,
                 "launches_timed": n.value,
+                "timed_every": max(1, args.time_every),
             },
         }
         if world == 1 and not args.no_processor_surface:

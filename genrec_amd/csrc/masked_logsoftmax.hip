@@ -590,13 +590,15 @@ static uint32_t packed_neg_inf(int dtype) {
 
 // ---- optional kernel timing ---------------------------------------------------
 #define TIMING_SLOTS 4096
-static bool g_timing_on = false;
+static int g_timing_every = 0;  // 0: off; k: every k-th call carries events
+static int g_timing_calls = 0;  // calls seen since the enable
 static int g_timing_n = 0;
 static hipEvent_t g_ev_start[TIMING_SLOTS], g_ev_stop[TIMING_SLOTS];
 static int g_ev_created = 0;
 
-extern "C" int grx_timing_enable(int on) {
-    g_timing_on = on != 0;
+extern "C" int grx_timing_enable(int every) {
+    g_timing_every = every > 0 ? every : 0;
+    g_timing_calls = 0;
     g_timing_n = 0;
     return GRX_OK;
 }
@@ -616,7 +618,8 @@ extern "C" int grx_timing_read(double* total_ms, int32_t* launches) {
 }
 
 static int timing_slot() {
-    if (!g_timing_on || g_timing_n >= TIMING_SLOTS) return -1;
+    if (g_timing_every == 0) return -1;
+    if ((g_timing_calls++ % g_timing_every) != 0 || g_timing_n >= TIMING_SLOTS) return -1;
     while (g_ev_created <= g_timing_n) {
         if (hipEventCreate(&g_ev_start[g_ev_created]) != hipSuccess) return -1;
         if (hipEventCreate(&g_ev_stop[g_ev_created]) != hipSuccess) return -1;

@@ -194,14 +194,17 @@ GRX_API int grx_constrained_candidates(const grx_trie* trie, grx_state* state, c
 
 /*
  * Kernel timing for benchmarks (no counterpart in the reference).  While
- * enabled, the two calls above attach HIP events to the dispatch of their
+ * enabled with every = k > 0, every k-th of the two calls above (the first
+ * one after the enable included) attaches HIP events to the dispatch of its
  * streaming kernel (compact form) or to the fill kernel's start and the
- * streaming kernel's end (dense form), up to 4096 calls per enable; the row
- * planning kernel is not included.  grx_timing_read synchronises on the
- * recorded events and returns the summed time in milliseconds and the number
- * of calls.  Process-wide and not thread-safe: a measurement hook, not an API.
+ * streaming kernel's end (dense form), up to 4096 timed calls per enable; the
+ * row planning kernel is not included.  An event pair costs about 5 us of
+ * stream time, hence the sampling.  every = 0 switches timing off.
+ * grx_timing_read synchronises on the recorded events and returns the summed
+ * time in milliseconds and the number of timed calls.  Process-wide and not
+ * thread-safe: a measurement hook, not an API.
  */
-GRX_API int grx_timing_enable(int on);
+GRX_API int grx_timing_enable(int every);
 GRX_API int grx_timing_read(double* total_ms, int32_t* launches);
 
 /*
