@@ -577,12 +577,33 @@ extern "C" int grx_beam_step(const grx_beam_step_args* args, void* stream) {
 // ------------------------------------------------------------------ init ---
 // Initial beam-search state (transformers generation/utils.py:3316-3351) written
 // into both halves of every double buffer by one launch.
-__global__ void beam_init_kernel(grx_beam_init_args a) {
+// With a plan request the first `plan_blocks` workgroups plan the rows of the first processor call
+// (they only read the caller's input_ids, so they run beside the initialisation instead of in a
+// kernel of their own): one thread per row in the count-based mode, one wave per row in the fixed-hint mode.
+__global__ void beam_init_kernel(grx_beam_init_args a, PlanCtx pc, grx_row_plan* __restrict__ plan_out, int plan_rows,
+                                 int64_t plan_stride, int plan_blocks) {
+    if ((int)blockIdx.x < plan_blocks) {
+        const int g = blockIdx.x * blockDim.x + threadIdx.x;
+        if (pc.mode == GRX_MODE_COUNT) {
+            if (g < plan_rows) {
+                if (g == 0) plan_count_bookkeeping(pc);
+                plan_out[g] = plan_count_row(pc, a.input_ids + (int64_t)g * plan_stride, a.prompt_len, g);
+            }
+        } else {
+            const int r = g / GRX_WAVE;
+            if (r < plan_rows) {
+                const grx_row_plan pl =
+                    plan_fixed_row(pc, a.input_ids + (int64_t)r * plan_stride, a.prompt_len, threadIdx.x & (GRX_WAVE - 1));
+                if ((threadIdx.x & (GRX_WAVE - 1)) == 0) plan_out[r] = pl;
+            }
+        }
+        return;
+    }
     const int64_t R = (int64_t)a.B * a.K;
     const int L = a.max_length, Lg = a.max_length - a.prompt_len;
     const int64_t total = R * L;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t n_threads = (int64_t)(gridDim.x - plan_blocks) * blockDim.x;
+    for (int64_t i = (int64_t)(blockIdx.x - plan_blocks) * blockDim.x + threadIdx.x; i < total; i += n_threads) {
         const int64_t r = i / L;
         const int p = (int)(i % L);
         const int64_t v = p < a.prompt_len ? a.input_ids[r * a.ids_stride + p] : a.fill_token;
@@ -627,18 +648,22 @@ extern "C" int grx_beam_init(const grx_beam_init_args* args, void* stream) {
     const int64_t total = (int64_t)a.B * a.K * a.max_length;
     int64_t blocks = (total + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(beam_init_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
-    GRX_CHECK_HIP(hipGetLastError());
+    PlanCtx pc;
+    memset(&pc, 0, sizeof(pc));
+    grx_row_plan* plan_out = nullptr;
+    int plan_rows = 0, plan_blocks = 0;
+    int64_t plan_stride = 0;
     if (a.plan_next != nullptr) {  // the first processor call sees the prompts themselves
-        PlanCtx pc;
-        grx_row_plan* plan_out = nullptr;
         const int per = a.plan_one_per_group ? a.K : 1;  // plan every K-th row only
-        const int n_rows = a.B * a.K / per;
-        int rc = grx_plan_ctx_for_next_call(who, a.plan_next, n_rows, &pc, &plan_out, (hipStream_t)stream);
+        plan_rows = a.B * a.K / per;
+        plan_stride = a.ids_stride * per;
+        const int rc = grx_plan_ctx_for_next_call(who, a.plan_next, plan_rows, &pc, &plan_out, (hipStream_t)stream);
         if (rc != GRX_OK) return rc;
-        rc = grx_launch_plan_kernel(pc, a.input_ids, a.ids_stride * per, n_rows, a.prompt_len, plan_out,
-                                    (hipStream_t)stream);
-        if (rc != GRX_OK) return rc;
+        const int64_t plan_threads = pc.mode == GRX_MODE_COUNT ? (int64_t)plan_rows : (int64_t)plan_rows * GRX_WAVE;
+        plan_blocks = (int)((plan_threads + 255) / 256);
     }
+    hipLaunchKernelGGL(beam_init_kernel, dim3((unsigned)(blocks + plan_blocks)), dim3(256), 0, (hipStream_t)stream, a, pc,
+                       plan_out, plan_rows, plan_stride, plan_blocks);
+    GRX_CHECK_HIP(hipGetLastError());
     return GRX_OK;
 }
