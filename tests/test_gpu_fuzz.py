@@ -153,12 +153,16 @@ def test_random_beam_searches_against_the_oracle(block):
         st = BeamSearchState(prompts.to(dev), K, L, c["eos"], 0, c["length_penalty"], c["early_stopping"],
                              shared_prompt=c["shared"])
         for step in range(c["max_new"]):
-            cnt = rng.integers(1, cmax + 1, size=R).astype(np.int32)
-            cnt[rng.random(R) < c["p_empty"]] = 0
-            tok = np.zeros((R, cmax), dtype=np.int32)
-            lp = np.zeros((R, cmax), dtype=np.float32)
-            dense = torch.full((R, V), float("-inf"))
-            for r in range(R):
+            # first step of groups that share a prompt: sometimes one candidate row per group, which all
+            # K beams extend from (the oracle sees that row K times)
+            one_per_group = step == 0 and c["shared"] and rng.random() < 0.5
+            n_rows = B if one_per_group else R
+            cnt = rng.integers(1, cmax + 1, size=n_rows).astype(np.int32)
+            cnt[rng.random(n_rows) < c["p_empty"]] = 0
+            tok = np.zeros((n_rows, cmax), dtype=np.int32)
+            lp = np.zeros((n_rows, cmax), dtype=np.float32)
+            dense = torch.full((n_rows, V), float("-inf"))
+            for r in range(n_rows):
                 n = int(cnt[r])
                 cols = np.sort(rng.choice(V - 2, size=n, replace=False) + 2)
                 if n and c["eos"] is not None and rng.random() < c["p_eos"]:
@@ -166,9 +170,10 @@ def test_random_beam_searches_against_the_oracle(block):
                 vals = (-rng.random(n) * 20).astype(np.float32)
                 tok[r, :n], lp[r, :n] = cols, vals
                 dense[r, torch.from_numpy(cols).long()] = torch.from_numpy(vals)
-            tr = ref.step(dense)
-            res = st.step(Candidates.from_parts(torch.from_numpy(cnt), torch.from_numpy(tok), torch.from_numpy(lp), dev), V)
-            tag = (c, step)
+            tr = ref.step(dense.repeat_interleave(K, dim=0) if one_per_group else dense)
+            res = st.step(Candidates.from_parts(torch.from_numpy(cnt), torch.from_numpy(tok), torch.from_numpy(lp), dev), V,
+                          shared_rows=one_per_group)
+            tag = (c, step, one_per_group)
             live = tr.topk_scores > LIVE
             assert torch.equal(res.topk_scores.cpu()[live], tr.topk_scores[live]), tag
             assert torch.equal(res.topk_token.cpu().long()[live], tr.topk_token[live]), tag
