@@ -247,6 +247,7 @@ def constrained_beam_search(
     early_stopping=False,
     num_return_sequences: Optional[int] = None,
     max_steps: Optional[int] = None,
+    first_step_shared: bool = False,
 ):
     """Trie-constrained beam search with the fused step.
 
@@ -258,23 +259,34 @@ def constrained_beam_search(
 
     ``max_steps`` fixes the number of iterations (a trie of L levels always
     takes L + 1) and avoids the per-step host check of the loop condition.
+    ``first_step_shared``: at step 0 ``logits_fn`` is handed the B prompt rows and
+    returns [B, V] (one row per group; the K copies would be identical).
     Returns ``(state, sequences, sequences_scores, beam_indices)``.
     """
     prompts = input_ids.repeat_interleave(num_beams, dim=0)
     if hasattr(processor, "reset"):
         processor.reset()  # before the state is built: its initialisation plans the first call
     state = BeamSearchState(prompts, num_beams, input_ids.shape[1] + max_new_tokens, eos_token_id, pad_token_id,
-                            length_penalty, early_stopping, shared_prompt=True, planner=processor)
+                            length_penalty, early_stopping, shared_prompt=True, planner=processor,
+                            first_step_shared=first_step_shared)
     from .logit_processor import Candidates
 
-    cand = Candidates(state.B * num_beams, max(processor.trie.max_fanout, 1), input_ids.device)
+    cmax = max(processor.trie.max_fanout, 1)
+    cand = Candidates(state.B * num_beams, cmax, input_ids.device)
     step = 0
     next_parent = None
     while True:
-        flat = state.flat_running_sequences()
-        logits = logits_fn(step, flat, next_parent)
-        processor.candidates_into(flat, logits, cand)
-        res = state.step(cand, logits.shape[-1], planner=processor)
+        if step == 0 and first_step_shared:
+            flat = state.prompt_rows()
+            logits = logits_fn(step, flat, next_parent)
+            first = Candidates(state.B, cmax, input_ids.device)
+            processor.candidates_into(flat, logits, first, one_row_per_group=True)
+            res = state.step(first, logits.shape[-1], planner=processor, shared_rows=True)
+        else:
+            flat = state.flat_running_sequences()
+            logits = logits_fn(step, flat, next_parent)
+            processor.candidates_into(flat, logits, cand)
+            res = state.step(cand, logits.shape[-1], planner=processor)
         next_parent = res.next_parent
         step += 1
         if max_steps is not None:

@@ -29,10 +29,12 @@ def _processor(name, fn, K, prefix, eos):
     return cls(fn, K, 3, prefix, eos, sync_errors=True)
 
 
+@pytest.mark.parametrize("first_step_shared", [False, True])
 @pytest.mark.parametrize("case", ["count_k4_lp1", "count_k16_lp0", "count_k16_lp1", "fixed_k8_lp1"])
-def test_fused_loop_reproduces_hf_generate(case):
+def test_fused_loop_reproduces_hf_generate(case, first_step_shared):
     """Raw logits recorded from generate() go through processor.candidates + grx_beam_step;
-    returned sequences / beam_indices are bit-exact and scores within 1e-5 on live beams."""
+    returned sequences / beam_indices are bit-exact and scores within 1e-5 on live beams.
+    ``first_step_shared``: step 0 runs on one logit row per prompt instead of the K copies."""
     from genrec_amd.beam import constrained_beam_search
     from genrec_amd.trie import FlatTrie, create_prefix_allowed_tokens_fn
 
@@ -51,10 +53,14 @@ def test_fused_loop_reproduces_hf_generate(case):
     def logits_fn(step, flat, next_parent):
         # the recorded logits are in HF's beam order of that step; parity on the live beams makes it ours too
         seen.append(flat.clone())
+        if step == 0 and first_step_shared:
+            assert flat.shape[0] == prompts.shape[0]
+            return logits[0][::K].contiguous()
         return logits[step]
 
     state, seqs, scores, bidx = constrained_beam_search(
-        logits_fn, proc, prompts, K, info["max_new_tokens"], eos, pad, info["length_penalty"], False
+        logits_fn, proc, prompts, K, info["max_new_tokens"], eos, pad, info["length_penalty"], False,
+        first_step_shared=first_step_shared,
     )
     assert len(seen) == info["steps"], "loop length differs from generate()"
     want_seqs = data[f"{case}.sequences"]
