@@ -211,7 +211,13 @@ __global__ __launch_bounds__(BS_THREADS) void beam_step_kernel(grx_beam_step_arg
     } else {
         // Wider groups: two passes over the existing candidates straight from global memory (they were
         // written a moment ago and sit in L2) -- per-thread maxima and threshold first, survivors second.
-        // Candidate c of the group is entry c - s_base[k] of beam k, the largest k with s_base[k] <= c.
+        // Two ways to deal the candidates to the threads, whichever needs fewer rounds of loads:
+        //  * packed: candidate c of the group (entry c - s_base[k] of beam k, the largest k with
+        //    s_base[k] <= c) goes to thread c mod 256 -- few candidates, few rounds;
+        //  * by column: thread t takes one entry per beam and 256-entry chunk, entry (t - 37 k) mod 256
+        //    of beam k (the rotation spreads short rows over all threads, which keeps the per-thread
+        //    maxima informative) -- the loads of different beams need no index search and are issued
+        //    back to back, which wins when the rows are long.
         for (int k = tid; k <= K; k += BS_THREADS) {
             int acc = 0;
             for (int j = 0; j < k; ++j) acc += s_cnt[j] < cmax ? s_cnt[j] : cmax;
@@ -219,6 +225,8 @@ __global__ __launch_bounds__(BS_THREADS) void beam_step_kernel(grx_beam_step_arg
         }
         __syncthreads();
         const int total = s_base[K];
+        const int n_chunk = (cmax + BS_THREADS - 1) / BS_THREADS;
+        const bool by_column = (total + BS_THREADS - 1) / BS_THREADS > 2 * ((K + 15) / 16) * n_chunk;
         auto packed_key = [&](int c) -> unsigned long long {
             int lo = 0, hi = K;
             while (hi - lo > 1) {
@@ -228,11 +236,41 @@ __global__ __launch_bounds__(BS_THREADS) void beam_step_kernel(grx_beam_step_arg
             const grx_cand e = g_cand[(int64_t)lo * bstride + 1 + (c - s_base[lo])];
             return make_key(__int_as_float(e.y) + s_runin[lo], (uint32_t)lo, (uint32_t)e.x);
         };
+        // keys of the entries that thread `tid` holds for beams k0 .. k0 + 15 in chunk j: the 16 loads
+        // are unconditional (the row header stands in where there is no entry) and issued together
+        constexpr int CB = 16;
+        auto column_keys = [&](int k0, int j, unsigned long long* kv) {
+            grx_cand e[CB];
+            bool ok[CB];
+#pragma unroll
+            for (int u = 0; u < CB; ++u) {
+                const int k = k0 + u < K ? k0 + u : K - 1;
+                const int i = j * BS_THREADS + ((tid - 37 * k) & (BS_THREADS - 1));
+                ok[u] = k0 + u < K && i < (s_cnt[k] < cmax ? s_cnt[k] : cmax);
+                e[u] = g_cand[(int64_t)k * bstride + (ok[u] ? 1 + i : 0)];
+            }
+#pragma unroll
+            for (int u = 0; u < CB; ++u) {
+                const int k = k0 + u < K ? k0 + u : K - 1;
+                kv[u] = ok[u] ? make_key(__int_as_float(e[u].y) + s_runin[k], (uint32_t)k, (uint32_t)e[u].x) : 0ull;
+            }
+        };
         unsigned long long tmax = 0;
+        if (by_column) {
+            for (int j = 0; j < n_chunk; ++j) {
+                for (int k0 = 0; k0 < K; k0 += CB) {
+                    unsigned long long kv[CB];
+                    column_keys(k0, j, kv);
+#pragma unroll
+                    for (int u = 0; u < CB; ++u) tmax = kv[u] > tmax ? kv[u] : tmax;
+                }
+            }
+        } else {
 #pragma unroll 4
-        for (int c = tid; c < total; c += BS_THREADS) {
-            const unsigned long long kv = packed_key(c);
-            tmax = kv > tmax ? kv : tmax;
+            for (int c = tid; c < total; c += BS_THREADS) {
+                const unsigned long long kv = packed_key(c);
+                tmax = kv > tmax ? kv : tmax;
+            }
         }
         s_tmax[tid] = tmax;
         STAMP(4);
@@ -246,13 +284,24 @@ __global__ __launch_bounds__(BS_THREADS) void beam_step_kernel(grx_beam_step_arg
         STAMP(5);
         __syncthreads();
         const unsigned long long thresh = s_thresh;
-#pragma unroll 4
-        for (int c = tid; c < total; c += BS_THREADS) {
-            const unsigned long long kv = packed_key(c);
-            if (kv >= thresh) {
+        auto keep = [&](unsigned long long kv) {
+            if (kv != 0 && kv >= thresh) {
                 const int at = atomicAdd(&s_nsurv, 1);
                 if (at < BS_SURV_CAP) s_surv[at] = kv;
             }
+        };
+        if (by_column) {
+            for (int j = 0; j < n_chunk; ++j) {
+                for (int k0 = 0; k0 < K; k0 += CB) {
+                    unsigned long long kv[CB];
+                    column_keys(k0, j, kv);
+#pragma unroll
+                    for (int u = 0; u < CB; ++u) keep(kv[u]);
+                }
+            }
+        } else {
+#pragma unroll 4
+            for (int c = tid; c < total; c += BS_THREADS) keep(packed_key(c));
         }
         STAMP(6);
         __syncthreads();
