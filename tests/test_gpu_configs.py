@@ -353,3 +353,49 @@ def test_c4_codebook_sweep_65536_rows(cb):
     info = _run_config(_synth_index(cb), "count", B=4096, K=16, dtype=torch.bfloat16, seed=10 + cb, sample_groups=4)
     want_v = {32: 151936, 64: 151936, 128: 152192, 512: 153728}[cb]
     assert info["R"] == 65536 and info["V"] == want_v and info["cmax"] == cb
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_c2_dense_processor_surface_8192_rows(dtype):
+    """The dense [R, V] result an unmodified transformers loop receives, at the benchmark's full size
+    (8192 x 152,640): finite exactly at the compact candidates' tokens, with their log-probs (rounded to
+    the output type), -inf everywhere else; the same call again into a caller-owned fp32 buffer."""
+    from genrec_amd.synth import sample_decode_rows
+
+    dev = _dev()
+    path = write_index_file("Instruments", tempfile.mkdtemp())
+    K, B = 16, 512
+    tok, trie, suffix, pidx, proc = _build(path, K, "count")
+    V, R = tok.vocab_size_padded, B * K
+    ids = torch.from_numpy(sample_decode_rows(trie, B, K, 1, prompt_len=61, seed=3)).to(dev)
+    x = _fill_logits(R, V, dtype, dev, 77)
+    proc.count = 1
+    cand = proc.candidates(ids, x)
+    proc.count = 1
+    out = proc(ids, x)
+    assert out.shape == x.shape and out.dtype == dtype
+    cnt = cand.count.long()
+    assert int(cnt.min()) >= 1
+    valid = torch.arange(cand.cmax, device=dev)[None, :] < cnt[:, None]
+    tokens = cand.tokens.long().clamp(min=0)
+
+    def check(result, tol):
+        for r0 in range(0, R, 1024):  # chunks bound the boolean temporaries
+            sl = slice(r0, r0 + 1024)
+            assert torch.equal(torch.isfinite(result[sl]).sum(dim=1), cnt[sl]), "allowed-token sets differ"
+            got = result[sl].gather(1, tokens[sl]).float()
+            want = cand.logp[sl]
+            err = ((got - want).abs() / tol(want))[valid[sl]]
+            assert float(err.max()) <= 1.0
+        assert bool((result[~torch.isfinite(result)] == float("-inf")).all())
+
+    if dtype == torch.bfloat16:
+        check(out, lambda w: w.abs() * 2.0 ** -8 + 1e-6)  # one bf16 rounding of the fp32 log-prob
+    else:
+        check(out, lambda w: torch.full_like(w, 4e-6))    # same arithmetic, different summation order
+    del out
+    proc.count = 1
+    wide = torch.empty((R, V), dtype=torch.float32, device=dev)
+    assert proc.call_into(ids, x, wide) is wide
+    check(wide, lambda w: torch.full_like(w, 4e-6))
+    proc.check_errors()
