@@ -15,6 +15,9 @@
 #define BS_MAXK 256
 #define BS_MAXKEEP 512
 #define BS_SURV_CAP 1024       // candidates ranked pairwise after the threshold cut
+#define BS_SMALL_K 16          // the instantiation for common searches: at most this many beams,
+#define BS_SMALL_KEEP 64       // ... kept candidates
+#define BS_SMALL_SURV 512      // ... and survivors
 #define BS_PREFETCH 16         // beams whose candidate rows are fetched in the opening batch of loads
 #define BS_TAIL_K 64           // beams / positions per row of the sequence tails staged in LDS
 #define BS_TAIL_W 16
@@ -50,31 +53,36 @@ extern "C" __attribute__((visibility("default"))) int grx_debug_read_stamps(unsi
 
 // Layout: the candidates of a group are the K x cmax block behind its first row;
 // slot c = beam * cmax + position holds a key, or 0 when position >= count[beam].
+// The LDS arrays are sized by the instantiation: MAXK beams, MAXKEEP kept candidates, SURV_CAP
+// survivors of the threshold cut, tail buffers for TAIL_K beams.  The common search (at most 16
+// beams, 64 kept candidates) gets by with 14 KB where the largest supported one takes 54 KB, and the
+// number of groups a CU works on at once follows from that.
+template <int MAXK, int MAXKEEP, int SURV_CAP, int TAIL_K>
 __global__ __launch_bounds__(BS_THREADS) void beam_step_kernel(grx_beam_step_args a, BeamDerived d, PlanCtx pc,
                                                                grx_row_plan* __restrict__ plan_out) {
-    __shared__ int s_cnt[BS_MAXK];
-    __shared__ int s_base[BS_MAXK + 1];
-    __shared__ float s_runin[BS_MAXK];
-    __shared__ unsigned char s_fdone_in[BS_MAXK];
+    __shared__ int s_cnt[MAXK];
+    __shared__ int s_base[MAXK + 1];
+    __shared__ float s_runin[MAXK];
+    __shared__ unsigned char s_fdone_in[MAXK];
     __shared__ unsigned long long s_tmax[BS_THREADS];
-    __shared__ unsigned long long s_surv[BS_SURV_CAP];
+    __shared__ unsigned long long s_surv[SURV_CAP];
     __shared__ int s_nsurv;
     __shared__ unsigned long long s_thresh;
     __shared__ unsigned long long s_red[2][BS_WAVES];
-    __shared__ float s_score[BS_MAXKEEP];
-    __shared__ int s_parent[BS_MAXKEEP];
-    __shared__ int s_tok[BS_MAXKEEP];
-    __shared__ unsigned char s_hit[BS_MAXKEEP];
-    __shared__ float s_rs[BS_MAXKEEP];
-    __shared__ float s_merged[BS_MAXK + BS_MAXKEEP];
-    __shared__ int s_run_idx[BS_MAXK];
-    __shared__ int s_fin_idx[BS_MAXK];
-    __shared__ float s_newfin[BS_MAXK];
-    __shared__ unsigned char s_newdone[BS_MAXK];
-    __shared__ int64_t s_rseq[BS_TAIL_K * BS_TAIL_W];
-    __shared__ int64_t s_fseq[BS_TAIL_K * BS_TAIL_W];
-    __shared__ int32_t s_rbidx[BS_TAIL_K * BS_TAIL_W];
-    __shared__ int32_t s_fbidx[BS_TAIL_K * BS_TAIL_W];
+    __shared__ float s_score[MAXKEEP];
+    __shared__ int s_parent[MAXKEEP];
+    __shared__ int s_tok[MAXKEEP];
+    __shared__ unsigned char s_hit[MAXKEEP];
+    __shared__ float s_rs[MAXKEEP];
+    __shared__ float s_merged[MAXK + MAXKEEP];
+    __shared__ int s_run_idx[MAXK];
+    __shared__ int s_fin_idx[MAXK];
+    __shared__ float s_newfin[MAXK];
+    __shared__ unsigned char s_newdone[MAXK];
+    __shared__ int64_t s_rseq[TAIL_K * BS_TAIL_W];
+    __shared__ int64_t s_fseq[TAIL_K * BS_TAIL_W];
+    __shared__ int32_t s_rbidx[TAIL_K * BS_TAIL_W];
+    __shared__ int32_t s_fbidx[TAIL_K * BS_TAIL_W];
 
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
@@ -191,13 +199,13 @@ __global__ __launch_bounds__(BS_THREADS) void beam_step_kernel(grx_beam_step_arg
         for (int u = 0; u < BS_PREFETCH; ++u) {
             if (rk[u] != 0 && rk[u] >= thresh) {
                 const int at = atomicAdd(&s_nsurv, 1);
-                if (at < BS_SURV_CAP) s_surv[at] = rk[u];
+                if (at < SURV_CAP) s_surv[at] = rk[u];
             }
         }
         STAMP(6);
         __syncthreads();
         const int M = s_nsurv;
-        if (M <= BS_SURV_CAP) {
+        if (M <= SURV_CAP) {
             for (int i = tid; i < M; i += BS_THREADS) {
                 const unsigned long long kv = s_surv[i];
                 int rank = 0;
@@ -287,7 +295,7 @@ __global__ __launch_bounds__(BS_THREADS) void beam_step_kernel(grx_beam_step_arg
         auto keep = [&](unsigned long long kv) {
             if (kv != 0 && kv >= thresh) {
                 const int at = atomicAdd(&s_nsurv, 1);
-                if (at < BS_SURV_CAP) s_surv[at] = kv;
+                if (at < SURV_CAP) s_surv[at] = kv;
             }
         };
         if (by_column) {
@@ -306,7 +314,7 @@ __global__ __launch_bounds__(BS_THREADS) void beam_step_kernel(grx_beam_step_arg
         STAMP(6);
         __syncthreads();
         const int M = s_nsurv;
-        if (M <= BS_SURV_CAP) {
+        if (M <= SURV_CAP) {
             for (int i = tid; i < M; i += BS_THREADS) {
                 const unsigned long long kv = s_surv[i];
                 int rank = 0;
@@ -534,8 +542,8 @@ __global__ __launch_bounds__(BS_THREADS) void beam_step_kernel(grx_beam_step_arg
             // node that has children: occurrences before the parent's stay invalid with one more token.
             // Rows that end in EOS take the EOS rule; everything else (parent already finished, leaf
             // reached without an EOS id) is rescanned the general way, one wave per row.
-            __shared__ int s_pcode[BS_MAXK];
-            __shared__ unsigned char s_rescan[BS_MAXK];
+            __shared__ int s_pcode[MAXK];
+            __shared__ unsigned char s_rescan[MAXK];
             for (int k = tid; k < K; k += BS_THREADS) s_pcode[k] = plan_out[row0 + k].code;  // this call's plans
             __syncthreads();
             for (int k = tid; k < K; k += BS_THREADS) {
@@ -609,7 +617,8 @@ extern "C" int grx_beam_step(const grx_beam_step_args* args, void* stream) {
                                                                        : (a.cur_len + 1 - a.prompt_len);
     d.heur_div = (float)pow((double)hyp, lp);
     d.reg_keys = (a.K <= BS_PREFETCH && a.cmax <= BS_THREADS && a.n_keep <= GRX_WAVE) ? 1 : 0;
-    d.tails_in_lds = (a.K <= BS_TAIL_K && a.cur_len + 1 - a.copy_from <= BS_TAIL_W &&
+    const bool small = a.K <= BS_SMALL_K && a.n_keep <= BS_SMALL_KEEP;
+    d.tails_in_lds = (a.K <= (small ? BS_SMALL_K : BS_TAIL_K) && a.cur_len + 1 - a.copy_from <= BS_TAIL_W &&
                       a.cur_len - a.prompt_len + 1 <= BS_TAIL_W) ? 1 : 0;
     PlanCtx pc;
     memset(&pc, 0, sizeof(pc));
@@ -618,7 +627,12 @@ extern "C" int grx_beam_step(const grx_beam_step_args* args, void* stream) {
         const int rc = grx_plan_ctx_for_next_call(who, a.plan_next, a.B * a.K, &pc, &plan_out, (hipStream_t)stream);
         if (rc != GRX_OK) return rc;
     }
-    hipLaunchKernelGGL(beam_step_kernel, dim3(a.B), dim3(BS_THREADS), 0, (hipStream_t)stream, a, d, pc, plan_out);
+    if (small)
+        hipLaunchKernelGGL((beam_step_kernel<BS_SMALL_K, BS_SMALL_KEEP, BS_SMALL_SURV, BS_SMALL_K>), dim3(a.B),
+                           dim3(BS_THREADS), 0, (hipStream_t)stream, a, d, pc, plan_out);
+    else
+        hipLaunchKernelGGL((beam_step_kernel<BS_MAXK, BS_MAXKEEP, BS_SURV_CAP, BS_TAIL_K>), dim3(a.B), dim3(BS_THREADS),
+                           0, (hipStream_t)stream, a, d, pc, plan_out);
     GRX_CHECK_HIP(hipGetLastError());
     return GRX_OK;
 }
