@@ -593,3 +593,36 @@ def test_a_plan_made_ahead_and_then_dropped_leaves_no_trace():
         _assert_dense_close(out, data[f"{case}.out.2"], FP32_TOL)
         assert proc.count == 3
         proc.check_errors()
+
+
+def test_subclassing_the_way_the_hint_analysis_script_does():
+    """analyze_rl_beam_hint.py:553-560 derives a seeded processor from ConstrainedLogitsProcessor by
+    assigning ``count`` in __init__ and overriding reset(); the same subclass of our class must behave
+    like the built-in ``initial_count=`` (golden case count_seeded2)."""
+    from genrec_amd.logit_processor import ConstrainedLogitsProcessor
+
+    class Seeded(ConstrainedLogitsProcessor):
+        def __init__(self, *args, initial_count=0, **kwargs):
+            super().__init__(*args, **kwargs)
+            self.initial_count = initial_count
+            self.count = initial_count
+
+        def reset(self):
+            self.count = self.initial_count
+
+    data, meta, trie, fn = _small_setup()
+    dev = _dev()
+    case = "count_seeded2"
+    proc = Seeded(prefix_allowed_tokens_fn=fn, num_beams=meta["K"], prefix_index=3, prefix_ids=meta["prefix"],
+                  eos_token_id=meta["eos"], initial_count=2)
+    info = meta["cases"][case]
+    for rep in range(2):
+        for i in range(info["steps"]):
+            ids = torch.from_numpy(data[f"{case}.ids.{i}"]).to(dev)
+            scores = torch.from_numpy(data[f"{case}.scores.{i}"]).to(dev)
+            _assert_dense_close(proc(ids, scores), data[f"{case}.out.{i}"], FP32_TOL)
+            if info["counts_after"][i] >= 0:
+                assert proc.count == info["counts_after"][i]
+        proc.reset()
+        assert proc.count == 2
+    proc.check_errors()
