@@ -115,7 +115,9 @@ def _random_beam_case(rng):
     K = int(rng.choice([1, 2, 3, 5, 8, 16, 17, 33, 65, 100]))
     B = int(rng.integers(1, 4))
     V = int(rng.integers(40, 2500))
-    cmax = int(rng.integers(1, min(V - 2, 300 if K <= 17 else 24) + 1))
+    # long rows for many beams now and then: that is what sends the kernel down its by-column route
+    widest = 300 if K <= 17 else (160 if rng.random() < 0.3 else 24)
+    cmax = int(rng.integers(1, min(V - 2, widest) + 1))
     prompt_len = int(rng.choice([1, 4, 19]))
     max_new = int(rng.integers(2, 7))
     eos = int(rng.integers(0, 2)) if rng.random() < 0.75 else None
