@@ -557,3 +557,40 @@ def test_first_step_from_one_row_per_group_equals_k_copies(kind):
         assert one.count == full.count
     one.check_errors()
     full.check_errors()
+
+
+@pytest.mark.parametrize("K,cmax", [(16, 256), (40, 256)])
+def test_adversarial_score_layout_takes_the_general_selection_route(K, cmax):
+    """The fast top-2K selection ranks only the candidates above a threshold taken from per-thread
+    maxima; when nearly all large scores sit with few threads, more candidates pass the threshold than
+    the pairwise ranking holds and the kernel falls back to plain repeated max extraction (16 beams:
+    a quarter of the lanes own every large score, > 1000 survivors at the second step).  With 40 beams
+    the rotated dealing spreads the same layout over all threads.  Same answer either way."""
+    from oracle.beam import RefBeamSearch
+
+    from genrec_amd.beam import BeamSearchState
+
+    dev = _dev()
+    B, V, eos = 2, 4000, 1
+    R = B * K
+    g = torch.Generator().manual_seed(5)
+    prompts = torch.randint(5, 90, (B, 4), generator=g).repeat_interleave(K, dim=0)
+    ref = RefBeamSearch(prompts, K, 4 + 3, eos, 0, 1.0, False)
+    st = BeamSearchState(prompts.to(dev), K, 4 + 3, eos, 0, 1.0, False)
+    for step in range(2):
+        cnt = torch.full((R,), cmax, dtype=torch.int32)
+        tok = (torch.arange(cmax, dtype=torch.int32)[None, :] * 3 + 2).repeat(R, 1)  # ascending, no eos
+        col = torch.arange(cmax)[None, :].expand(R, cmax)
+        # entries in a quarter of the columns (mod 64) are large, the rest small
+        high = (col % 64) < 16
+        lp = torch.where(high, -torch.rand(R, cmax, generator=g), -10.0 - torch.rand(R, cmax, generator=g))
+        dense = torch.full((R, V), float("-inf"))
+        dense.scatter_(1, tok.long(), lp)
+        tr = ref.step(dense)
+        res = st.step(Candidates.from_parts(cnt, tok, lp, dev), V)
+        live = tr.topk_scores > LIVE
+        assert torch.equal(res.topk_scores.cpu()[live], tr.topk_scores[live])
+        assert torch.equal(res.topk_token.cpu().long()[live], tr.topk_token[live])
+        assert torch.equal(res.topk_parent.cpu().long()[live], tr.topk_parent[live])
+        run_live = ref.running_beam_scores > LIVE
+        assert torch.equal(st.running_sequences.cpu()[run_live], ref.running_sequences[run_live])
