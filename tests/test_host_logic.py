@@ -282,3 +282,69 @@ def test_saved_metric_files_have_the_layout_pandas_gives_the_reference(tmp_path)
         df.index.name = "path"
         want = df.to_csv(sep="\t", encoding="utf-8")
         assert open(tmp_path / sub / "metrics.tsv", newline="").read() == want
+
+
+def test_entry_points_reject_bad_arguments_on_the_host():
+    """Every shape / pointer check runs before the first device call, so it can be exercised without a
+    GPU: a caller that passes garbage gets GRX_E_INVALID (or _UNSUPPORTED / _WORKSPACE) and a message,
+    never a kernel launched on bad operands."""
+    import numpy as np
+
+    from genrec_amd import _lib
+
+    lib = _lib.lib()
+    INVALID, UNSUPPORTED = -1, -3
+
+    def msg():
+        return lib.grx_last_error().decode()
+
+    def trie(off, tok):
+        off = np.asarray(off, dtype=np.int32)
+        tok = np.asarray(tok, dtype=np.int32)
+        out = C.c_void_p()
+        rc = lib.grx_trie_create(off.ctypes.data, tok.ctypes.data if len(tok) else None, len(off) - 1, len(tok),
+                                 C.byref(out))
+        assert out.value is None or rc == 0
+        return rc
+
+    # malformed child tables (a well-formed one would go on to allocate device memory)
+    assert trie([0, 2, 2, 2], [7, 5]) == INVALID and "strictly increasing" in msg()
+    assert trie([0, 2, 2, 2], [-1, 5]) == INVALID and "negative token" in msg()
+    assert trie([0, 1, 3, 2], [4, 5]) == INVALID                       # offsets not monotone / not ending at n_edges
+    assert trie([1, 2, 2], [4]) == INVALID and "start at 0" in msg()
+    assert trie([0, 0, 1], [4]) == INVALID and "backwards" in msg()      # node 1 pointing at itself
+    assert lib.grx_trie_create(None, None, 3, 1, C.byref(C.c_void_p())) == INVALID  # n_nodes != n_edges + 1
+
+    # beam step: shapes and aliasing
+    a = _lib.GrxBeamStepArgs()
+    a.B, a.K, a.V, a.n_keep, a.cmax = 1, 4, 100, 8, 4
+    a.cur_len, a.prompt_len, a.max_length, a.copy_from = 3, 3, 8, 3
+    a.eos_token_id, a.early_stopping, a.length_penalty, a.cand_stride = 1, 0, 1.0, 16
+    assert lib.grx_beam_step(C.byref(a), None) == INVALID and "null buffer" in msg()
+    a.K = 300
+    assert lib.grx_beam_step(C.byref(a), None) == UNSUPPORTED and "at most" in msg()
+    a.K, a.n_keep = 4, 2
+    assert lib.grx_beam_step(C.byref(a), None) == INVALID and "n_keep" in msg()
+    a.n_keep, a.cur_len = 8, 8
+    assert lib.grx_beam_step(C.byref(a), None) == INVALID and "max_length" in msg()
+    a.cur_len, a.cand_stride = 3, 4
+    assert lib.grx_beam_step(C.byref(a), None) == INVALID and "cand_stride" in msg()
+    a.cand_stride, a.cand_shared = 16, 7
+    assert lib.grx_beam_step(C.byref(a), None) == INVALID and "cand_shared" in msg()
+    a.cand_shared, a.V = 0, 1 << 25
+    assert lib.grx_beam_step(C.byref(a), None) == UNSUPPORTED and "2^24" in msg()
+
+    # scoring kernels
+    assert lib.grx_group_advantage(None, None, 10, 1, 4, 1, 1e-4, None, None, None, None, None) == INVALID
+    assert "do not split" in msg()
+    assert lib.grx_group_advantage(None, None, 8, 1, 4, 5, 1e-4, None, None, None, None, None) == INVALID
+    assert lib.grx_group_advantage(None, None, 8, 1, 4, 1, 1e-4, None, None, None, None, None) == INVALID
+    assert "null input" in msg()
+    assert lib.grx_sid_rewards(None, None, 4, None, None, 4, 8, 300, 1, None, None, None, None, 1, None) == UNSUPPORTED
+    assert lib.grx_hit_ranks(None, None, -1, 4, 4, None, None, None) == INVALID
+    assert lib.grx_group_normalize_tokenwise(None, None, 9, 4, 4, 1e-4, None, None) == INVALID
+    # empty work is fine and touches nothing
+    assert lib.grx_group_advantage(None, None, 0, 1, 4, 1, 1e-4, None, None, None, None, None) == 0
+    assert lib.grx_hit_ranks(None, None, 0, 4, 4, None, None, None) == 0
+    a.B, a.V = 0, 100
+    assert lib.grx_beam_step(C.byref(a), None) == 0
