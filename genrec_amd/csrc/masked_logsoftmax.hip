@@ -677,6 +677,14 @@ static int run_step(const char* who, const grx_trie* trie, grx_state* state, con
     if (rc != GRX_OK) return rc;
     GRX_REQUIRE(con->eos_token_id < rows->V, GRX_E_INVALID, "%s: eos_token_id %d outside V=%d", who,
                 con->eos_token_id, rows->V);
+    const bool penalise = con->repetition_penalty != 0.f && con->repetition_penalty != 1.f;
+    if (penalise) {
+        GRX_REQUIRE(con->repetition_penalty > 0.f, GRX_E_INVALID, "%s: repetition_penalty must be positive", who);
+        GRX_REQUIRE(con->penalty_skip >= 0, GRX_E_INVALID, "%s: penalty_skip must be >= 0", who);
+        GRX_REQUIRE(rows->T - con->penalty_skip <= GRX_MAX_PENALTY_TOKENS, GRX_E_UNSUPPORTED,
+                    "%s: repetition penalty over more than %d tokens per row", who, GRX_MAX_PENALTY_TOKENS);
+    }
+    // Nothing below this line fails on an argument: the call now counts and its kernels are enqueued.
     // phase 0: one small kernel works out the trie node of every row
     grx_row_plan* plan = rows->R > 0
                              ? reinterpret_cast<grx_row_plan*>(reinterpret_cast<char*>(workspace) + GRX_WS_PLAN_OFFSET)
@@ -691,11 +699,7 @@ static int run_step(const char* who, const grx_trie* trie, grx_state* state, con
     a.st = state ? state->dev : nullptr;
     a.reset_aware = (con->mode == GRX_MODE_COUNT && con->n_prefix >= 0) ? 1 : 0;
     a.penalty = 0.f;
-    if (con->repetition_penalty != 0.f && con->repetition_penalty != 1.f) {
-        GRX_REQUIRE(con->repetition_penalty > 0.f, GRX_E_INVALID, "%s: repetition_penalty must be positive", who);
-        GRX_REQUIRE(con->penalty_skip >= 0, GRX_E_INVALID, "%s: penalty_skip must be >= 0", who);
-        GRX_REQUIRE(rows->T - con->penalty_skip <= GRX_MAX_PENALTY_TOKENS, GRX_E_UNSUPPORTED,
-                    "%s: repetition penalty over more than %d tokens per row", who, GRX_MAX_PENALTY_TOKENS);
+    if (penalise) {
         a.penalty = con->repetition_penalty;
         a.pen_from = con->penalty_skip;
         a.ids = rows->input_ids;

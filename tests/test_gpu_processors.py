@@ -626,3 +626,76 @@ def test_subclassing_the_way_the_hint_analysis_script_does():
         proc.reset()
         assert proc.count == 2
     proc.check_errors()
+
+
+def test_step_entry_points_reject_bad_operands_before_launching():
+    """With a real trie and state in hand: operands that do not fit what the kernels assume are
+    refused on the host (status + message), never launched."""
+    import ctypes as C
+
+    from genrec_amd import _lib
+
+    data, meta, trie, fn = _small_setup()
+    dev = _dev()
+    lib = _lib.lib()
+    proc = _make("count_rl", fn, meta)
+    V, K = meta["V"], meta["K"]
+    R, T = 2 * K, 6
+    ids = torch.zeros((R, T), dtype=torch.int64, device=dev)
+    x = torch.zeros((R, V), dtype=torch.float32, device=dev)
+    handle, st = trie.device_handle(dev), proc._state(0).ptr
+    ws = torch.zeros(int(lib.grx_workspace_bytes(R)) + 16, dtype=torch.uint8, device=dev)
+    stride = int(lib.grx_candidate_stride(trie.max_fanout))
+    cand = torch.zeros((R, stride, 2), dtype=torch.int32, device=dev)
+
+    def rows(**kw):
+        r = _lib.GrxRows()
+        r.input_ids, r.ids_stride, r.R, r.T = ids.data_ptr(), T, R, T
+        r.scores, r.scores_stride, r.V, r.dtype = x.data_ptr(), V, V, _lib.GRX_F32
+        for k, v in kw.items():
+            setattr(r, k, v)
+        return r
+
+    def call(r, con=None, cand_ptr=None, cand_stride=stride, cmax=trie.max_fanout, ws_ptr=None, ws_bytes=None):
+        con = con or proc._constraint()
+        return lib.grx_constrained_candidates(handle, st, C.byref(r), C.byref(con),
+                                              cand.data_ptr() if cand_ptr is None else cand_ptr, cand_stride, cmax,
+                                              ws.data_ptr() if ws_ptr is None else ws_ptr,
+                                              ws.numel() if ws_bytes is None else ws_bytes, None)
+
+    def msg():
+        return lib.grx_last_error().decode()
+
+    calls_before = proc._read_state(0)[3]
+    assert call(rows(V=trie.max_token)) == -1 and "token id" in msg()            # trie tokens outside the rows
+    assert call(rows(scores_stride=V - 1)) == -1 and "stride" in msg()
+    assert call(rows(ids_stride=T - 1)) == -1 and "stride" in msg()
+    assert call(rows(dtype=9)) == -1 and "dtype" in msg()
+    assert call(rows(scores=None)) == -1
+    assert call(rows(), ws_bytes=64) == -4 and "workspace" in msg()
+    assert call(rows(), ws_ptr=ws.data_ptr() + 4) == -4
+    assert call(rows(), cand_ptr=cand.data_ptr() + 8) == -1 and "128-byte" in msg()
+    assert call(rows(), cand_stride=stride + 8) == -1 and "multiple of 16" in msg()
+    assert call(rows(), cmax=0) == -1
+    con = proc._constraint()
+    con.eos_token_id = V
+    assert call(rows(), con=con) == -1 and "eos_token_id" in msg()
+    con = proc._constraint()
+    con.n_prefix = 17
+    assert call(rows(), con=con) == -3
+    con = proc._constraint()
+    con.mode = 5
+    assert call(rows(), con=con) == -1
+    con = proc._constraint()
+    con.repetition_penalty = -2.0
+    assert call(rows(), con=con) == -1 and "positive" in msg()
+    out = torch.empty_like(x)
+    assert lib.grx_constrained_logsoftmax(handle, st, C.byref(rows()), C.byref(proc._constraint()), x.data_ptr(), V, 0,
+                                          ws.data_ptr(), ws.numel(), None) == -1 and "alias" in msg()
+    assert lib.grx_constrained_logsoftmax(handle, st, C.byref(rows()), C.byref(proc._constraint()), out.data_ptr(), V - 1,
+                                          0, ws.data_ptr(), ws.numel(), None) == -1
+    assert lib.grx_constrained_logsoftmax(handle, st, C.byref(rows()), C.byref(proc._constraint()), out.data_ptr(), V,
+                                          _lib.GRX_BF16, ws.data_ptr(), ws.numel(), None) == -3
+    torch.cuda.synchronize()
+    assert not bool(cand.any()), "a refused call must not have written anything"
+    assert proc._read_state(0)[3] == calls_before, "a refused call must not count as a processor call"
