@@ -1,0 +1,32 @@
+"""bench.py's multi-rank flow (barriers, per-rank shards, reward all-gather, max-over-ranks timing,
+rank-0 JSON line) rehearsed with two ranks sharing the one GPU of the test box.  RCCL refuses two ranks
+on one device, so the rehearsal swaps the backend for gloo (GENREC_BENCH_BACKEND); everything else is
+the code path of `--gpus N`."""
+
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_two_rank_bench_line():
+    env = dict(os.environ, GENREC_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29611", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10",
+           "--warmup", "5", "--batch", "32"]
+    run = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=280)
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-4000:]
+    lines = [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line, from rank 0"
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 10 and d["warmup"] == 5 and d["scaling"] == "weak"
+    assert d["config"]["parallelism"].startswith("dp2")
+    # whole-job value: both ranks' steps over the slowest rank's time
+    assert abs(d["value"] - 2 * 10 / (d["ms_per_step"] * 10 / 1e3)) <= 1e-6 * d["value"]
+    assert d["roofline"]["launches_timed"] >= 2 and d["roofline"]["achieved"] > 0
+    assert "cpu_baseline" not in d  # rank 0 at N = 1 only
