@@ -533,9 +533,11 @@ __global__ __launch_bounds__(BS_THREADS) void beam_step_kernel(grx_beam_step_arg
         // the sequence rows were written by other threads of this workgroup (barrier above STAMP(13))
         const int T_next = a.cur_len + 1;
         if (pc.mode == GRX_MODE_COUNT) {
+            // the streaming kernel walks the rows itself; what it needs from here is the once-per-call
+            // bookkeeping and the lowest row that ends in prefix_ids
             if (b == 0 && tid == 0) plan_count_bookkeeping(pc);
             for (int k = tid; k < K; k += BS_THREADS)
-                plan_out[row0 + k] = plan_count_row(pc, a.run_seq_out + (row0 + k) * L, T_next, (int)(row0 + k));
+                count_row_match(pc, a.run_seq_out + (row0 + k) * L, T_next, (int)(row0 + k));
         } else {
             // Fixed-hint mode.  A new row is its parent's row plus one token, so its first valid prefix
             // occurrence is the parent's whenever the parent's node continues with that token onto a
@@ -569,7 +571,7 @@ __global__ __launch_bounds__(BS_THREADS) void beam_step_kernel(grx_beam_step_arg
                         }
                     }
                 }
-                pl.code0 = pl.code;
+                pl.pad = 0;
                 s_rescan[k] = known ? 0 : 1;
                 if (known) plan_out[row0 + k] = pl;
             }
@@ -650,7 +652,7 @@ __global__ void beam_init_kernel(grx_beam_init_args a, PlanCtx pc, grx_row_plan*
         if (pc.mode == GRX_MODE_COUNT) {
             if (g < plan_rows) {
                 if (g == 0) plan_count_bookkeeping(pc);
-                plan_out[g] = plan_count_row(pc, a.input_ids + (int64_t)g * plan_stride, a.prompt_len, g);
+                count_row_match(pc, a.input_ids + (int64_t)g * plan_stride, a.prompt_len, g);
             }
         } else {
             const int r = g / GRX_WAVE;

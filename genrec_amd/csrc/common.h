@@ -226,13 +226,13 @@ __device__ __forceinline__ int resolve_fixed_row(const TrieView& tv, const int64
 }
 
 // ------------------------------------------------------------ row plans ---
-// Plan of one row for the streaming kernel: the governing trie node (or a negative
-// GRX_RES_* code), its child range, and the node of the row's count == 0 window.
+// Plan of one row for the streaming kernel (fixed-hint mode): the governing trie node (or a
+// negative GRX_RES_* code) and its child range.
 struct grx_row_plan {
     int32_t code;
     int32_t off;
     int32_t n;
-    int32_t code0;
+    int32_t pad;
 };
 
 // What a kernel needs to plan rows for a processor call (kernel argument, by value).
@@ -248,31 +248,32 @@ struct PlanCtx {
     PrefixArg pfx;
 };
 
-// Count-based mode (logit_processor.py:38-44), one thread per row: the window is the
-// last prefix_index + count tokens, where count is the shared counter after the previous
-// call.  Rows whose last prefix_index tokens equal prefix_ids reset the shared counter
-// for themselves and every later row (logit_processor.py:39-40); the lowest such row is
-// min-reduced into first_match[slot], and every row also gets the node of its count == 0
-// window (code0) for the streaming kernel to pick.
+// Count-based mode (logit_processor.py:38-44).  The shared counter a call starts with is the
+// counter after the previous call, unless the caller set it in between.
 __device__ __forceinline__ int plan_start_count(const PlanCtx& c) {
     return c.count_set ? c.count_value : state_count_after(*c.st, (c.slot + 2) % 3);
 }
 
-__device__ __forceinline__ grx_row_plan plan_count_row(const PlanCtx& c, const int64_t* __restrict__ row, int T, int r) {
-    const int count = plan_start_count(c);
+// Preparation of a count-based call, one thread per row: rows whose last prefix_index tokens
+// equal prefix_ids reset the shared counter for themselves and every later row
+// (logit_processor.py:39-40); the lowest such row is min-reduced into first_match[slot].
+// Nothing to do when prefix_ids is None.
+__device__ __forceinline__ void count_row_match(const PlanCtx& c, const int64_t* __restrict__ row, int T, int r) {
+    if (c.pfx.n < 0) return;
     const int s0 = py_tail_start(c.prefix_index, T);
-    if (c.pfx.n >= 0) {
-        bool match = (T - s0) == c.pfx.n;
-        for (int i = 0; match && i < c.pfx.n; ++i) match = row[s0 + i] == c.pfx.ids[i];
-        if (match) atomicMin(&c.st->first_match[c.slot], r);
-    }
+    bool match = (T - s0) == c.pfx.n;
+    for (int i = 0; match && i < c.pfx.n; ++i) match = row[s0 + i] == c.pfx.ids[i];
+    if (match) atomicMin(&c.st->first_match[c.slot], r);
+}
+
+// The node that governs row r of a prepared count-based call (first_match[slot] is final): the
+// window is the last prefix_index + count tokens, count = 0 from the first matching row on
+// (logit_processor.py:39-41).  Every operand is uniform over the workgroup that calls it.
+__device__ __forceinline__ int count_row_node(const PlanCtx& c, const int64_t* __restrict__ row, int T, int r) {
+    int count = plan_start_count(c);
+    if (c.pfx.n >= 0 && r >= c.st->first_match[c.slot]) count = 0;
     const int start = py_tail_start(c.prefix_index + count, T);
-    grx_row_plan pl;
-    pl.code = trie_walk(c.tv, row + start, T - start);
-    pl.off = pl.code >= 0 ? c.tv.off[pl.code] : 0;
-    pl.n = pl.code >= 0 ? c.tv.off[pl.code + 1] - pl.off : 0;
-    pl.code0 = (c.pfx.n >= 0 && start != s0) ? trie_walk(c.tv, row + s0, T - s0) : pl.code;
-    return pl;
+    return trie_walk(c.tv, row + start, T - start);
 }
 
 // Once per planned count-based call: record the counter the call runs with and re-arm the
@@ -292,6 +293,6 @@ __device__ __forceinline__ grx_row_plan plan_fixed_row(const PlanCtx& c, const i
     pl.code = code;
     pl.off = code >= 0 ? c.tv.off[code] : 0;
     pl.n = code >= 0 ? c.tv.off[code + 1] - pl.off : (code == GRX_RES_EOS ? 1 : 0);
-    pl.code0 = code;
+    pl.pad = 0;
     return pl;
 }

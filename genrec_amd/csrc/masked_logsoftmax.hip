@@ -35,10 +35,11 @@ enum { OUT_COMPACT = 0, OUT_FULL_F32 = 1, OUT_FULL_SAME = 2 };
 struct MlsArgs {
     const int32_t* tok;    // child tokens of the trie (CSR)
     const int32_t* off;    // child offsets of the trie (CSR)
-    const grx_row_plan* plan;  // [R] from the planning kernel of this call
+    const grx_row_plan* plan;  // fixed-hint mode: [R] from the planning kernel of this call
     grx_state_words* st;   // may be null (fixed-hint without error reporting)
-    int slot;              // state slot this call owns (count mode)
-    int reset_aware;       // count mode with prefix_ids: rows from first_match[slot] on use their count == 0 window
+    int walk;              // count mode: every workgroup works out its row's node itself (pc, ids, T) ...
+    int bookkeep;          // ... and workgroup 0 records the call's counter / re-arms the next match word
+    PlanCtx pc;
     int R;
     const void* scores;
     int64_t scores_stride;
@@ -277,15 +278,21 @@ __global__ __launch_bounds__(MLS_THREADS) void masked_lsm_kernel(MlsArgs a) {
         for (int u = 0; u < MLS_UNROLL; ++u) v_head[u] = vp.load(v_lo + tid + u * MLS_THREADS);
     }
 
-    // Which trie node governs this row: planned by the kernel that ran just before
-    // (one 16-byte scalar load, which does not queue behind the stream loads).
-    const grx_row_plan pl = a.plan[r];
-    int code = pl.code, c_off = pl.off, c_n = pl.n;
-    if (a.reset_aware && r >= a.st->first_match[a.slot] && pl.code0 != pl.code) {
-        // the shared counter was reset at or before this row (logit_processor.py:39-41)
-        code = pl.code0;
+    // Which trie node governs this row.  Count-based mode: walked here -- every operand is uniform
+    // over the workgroup, so the walk is scalar loads and scalar arithmetic that run beside the
+    // stream loads already in flight, and the kernel's duration is set by the stream either way.
+    // Fixed-hint mode: planned by the kernel that ran just before (one 16-byte scalar load).
+    int code, c_off, c_n;
+    if (a.walk) {
+        code = count_row_node(a.pc, a.ids + (int64_t)r * a.ids_stride, a.T, r);
         c_off = code >= 0 ? a.off[code] : 0;
-        c_n = code >= 0 ? a.off[code + 1] - c_off : (code == GRX_RES_EOS ? 1 : 0);
+        c_n = code >= 0 ? a.off[code + 1] - c_off : 0;
+        if (a.bookkeep && blockIdx.x == 0 && tid == 0) plan_count_bookkeeping(a.pc);
+    } else {
+        const grx_row_plan pl = a.plan[r];
+        code = pl.code;
+        c_off = pl.off;
+        c_n = pl.n;
     }
     MSTAMP(1);
     if (code < 0 && code != GRX_RES_EOS && tid == 0 && part == 0) {
@@ -689,22 +696,22 @@ static int run_step(const char* who, const grx_trie* trie, grx_state* state, con
     grx_row_plan* plan = rows->R > 0
                              ? reinterpret_cast<grx_row_plan*>(reinterpret_cast<char*>(workspace) + GRX_WS_PLAN_OFFSET)
                              : nullptr;
-    rc = grx_plan_rows(trie, state, rows, con, plan, stream, &a.slot);
+    rc = grx_plan_rows(trie, state, rows, con, plan, stream, &a.pc, &a.bookkeep);
     if (rc != GRX_OK) return rc;
     if (rows->R == 0) return GRX_OK;
+    a.walk = con->mode == GRX_MODE_COUNT ? 1 : 0;
+    a.ids = rows->input_ids;
+    a.ids_stride = rows->ids_stride;
+    a.T = rows->T;
 
     a.tok = trie->child_tok;
     a.off = trie->child_off;
     a.plan = plan;
     a.st = state ? state->dev : nullptr;
-    a.reset_aware = (con->mode == GRX_MODE_COUNT && con->n_prefix >= 0) ? 1 : 0;
     a.penalty = 0.f;
     if (penalise) {
         a.penalty = con->repetition_penalty;
         a.pen_from = con->penalty_skip;
-        a.ids = rows->input_ids;
-        a.ids_stride = rows->ids_stride;
-        a.T = rows->T;
     }
     a.R = rows->R;
     a.scores = rows->scores;

@@ -5,11 +5,12 @@
 
 PrefixArg grx_prefix_arg(const grx_constraint* con);
 
-// Open a processor call on `stream`: picks the state slot a count-based call owns,
-// advances the host-side call counter and enqueues the kernel that writes one
-// grx_row_plan per row (and, count-based, finds the rows that end in prefix_ids).
+// Open a processor call on `stream`: picks the state slot a count-based call owns, advances the
+// host-side call counter and prepares the call -- fixed-hint: the kernel that writes one grx_row_plan
+// per row; count-based: the kernel that finds the rows ending in prefix_ids (the streaming kernel
+// walks the rows itself with *ctx_out, and does the once-per-call bookkeeping when *bookkeep_out).
 int grx_plan_rows(const grx_trie* trie, grx_state* state, const grx_rows* rows, const grx_constraint* con,
-                  grx_row_plan* plan, hipStream_t stream, int* slot_out);
+                  grx_row_plan* plan, hipStream_t stream, PlanCtx* ctx_out, int* bookkeep_out);
 
 // Planning context for the processor call that will follow on `state` (its slot is the one the
 // next count-based call owns; the host-side call counter is left alone), and the plan buffer

@@ -183,12 +183,14 @@ extern "C" int grx_state_read(grx_state* s, int32_t out[4], void* stream) {
 // ------------------------------------------------------------- row plans ---
 // Which trie node governs each row, worked out ahead of the streaming kernel so
 // that kernel starts streaming after a single 16-byte load per row.
-__global__ void plan_count_rows_kernel(PlanCtx c, const int64_t* __restrict__ ids, int64_t ids_stride, int R, int T,
-                                       grx_row_plan* __restrict__ plan) {
+// Preparation of a count-based call whose rows nobody prepared ahead: the prefix_ids match
+// reduction and the once-per-call bookkeeping.  The rows themselves are walked by the
+// streaming kernel.
+__global__ void count_match_rows_kernel(PlanCtx c, const int64_t* __restrict__ ids, int64_t ids_stride, int R, int T) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= R) return;
     if (r == 0) plan_count_bookkeeping(c);
-    plan[r] = plan_count_row(c, ids + (int64_t)r * ids_stride, T, r);
+    count_row_match(c, ids + (int64_t)r * ids_stride, T, r);
 }
 
 __global__ void plan_fixed_rows_kernel(PlanCtx c, const int64_t* __restrict__ ids, int64_t ids_stride, int R, int T,
@@ -261,8 +263,8 @@ int grx_launch_plan_kernel(const PlanCtx& ctx, const int64_t* ids, int64_t ids_s
     const int threads = 256;
     if (R <= 0) return GRX_OK;
     if (ctx.mode == GRX_MODE_COUNT) {
-        hipLaunchKernelGGL(plan_count_rows_kernel, dim3((R + threads - 1) / threads), dim3(threads), 0, stream, ctx, ids,
-                           ids_stride, R, T, plan);
+        hipLaunchKernelGGL(count_match_rows_kernel, dim3((R + threads - 1) / threads), dim3(threads), 0, stream, ctx, ids,
+                           ids_stride, R, T);
     } else {
         const int64_t total = (int64_t)R * GRX_WAVE;
         hipLaunchKernelGGL(plan_fixed_rows_kernel, dim3((unsigned)((total + threads - 1) / threads)), dim3(threads), 0,
@@ -272,34 +274,41 @@ int grx_launch_plan_kernel(const PlanCtx& ctx, const int64_t* ids, int64_t ids_s
     return GRX_OK;
 }
 
-// Open a processor call on `stream`: in the count-based mode pick the state slot the call owns
-// and advance the host-side call counter; enqueue the row planning kernel unless the rows
-// arrive planned (grx_rows.planned).
+// Open a processor call on `stream`.  Count-based mode: pick the state slot the call owns, advance
+// the host-side call counter and hand back the context with which the streaming kernel walks its
+// rows; unless the rows arrive prepared (grx_rows.planned), the call is prepared here -- by the
+// match kernel when prefix_ids is given, else by the streaming kernel itself (*bookkeep_out).
+// Fixed-hint mode: enqueue the row planning kernel unless the rows arrive planned.
 int grx_plan_rows(const grx_trie* trie, grx_state* state, const grx_rows* rows, const grx_constraint* con,
-                  grx_row_plan* plan, hipStream_t stream, int* slot_out) {
-    *slot_out = 0;
+                  grx_row_plan* plan, hipStream_t stream, PlanCtx* ctx_out, int* bookkeep_out) {
     int slot = 0;
+    *bookkeep_out = 0;
     if (con->mode == GRX_MODE_COUNT) {
         slot = (int)(state->calls % 3u);
-        *slot_out = slot;
         state->calls += 1;
     }
-    // a counter set since the last call reaches this call's planning (done ahead or now) and ends here
+    // a counter set since the last call reaches this call (prepared ahead or now) and ends here
     const PlanCtx ctx = make_plan_ctx(trie, state, con, slot);
+    *ctx_out = ctx;
     if (state) state->count_pending = false;
     if (con->mode == GRX_MODE_COUNT) {
-        if (state->ahead_open && !rows->planned) {  // a plan made ahead for this slot is not the one that runs
+        if (state->ahead_open && !rows->planned) {  // a preparation made ahead for this slot is not the one that runs
             hipLaunchKernelGGL(state_rearm_kernel, dim3(1), dim3(1), 0, stream, state->dev, slot);
             GRX_CHECK_HIP(hipGetLastError());
         }
         state->ahead_open = false;
-    }
-    if (con->mode == GRX_MODE_COUNT && rows->R == 0) {
-        // a planned empty call cannot exist: whoever planned had no rows to attach the bookkeeping to
-        hipLaunchKernelGGL(state_bookkeeping_kernel, dim3(1), dim3(1), 0, stream, state->dev, slot, ctx.count_set,
-                           ctx.count_value);
-        GRX_CHECK_HIP(hipGetLastError());
-        return GRX_OK;
+        if (rows->R == 0) {
+            // an empty call cannot arrive prepared: whoever prepared had no rows to attach the bookkeeping to
+            hipLaunchKernelGGL(state_bookkeeping_kernel, dim3(1), dim3(1), 0, stream, state->dev, slot, ctx.count_set,
+                               ctx.count_value);
+            GRX_CHECK_HIP(hipGetLastError());
+            return GRX_OK;
+        }
+        if (rows->planned) return GRX_OK;
+        if (con->n_prefix < 0) {  // no match reduction to wait for: the streaming kernel does the bookkeeping
+            *bookkeep_out = 1;
+            return GRX_OK;
+        }
     }
     if (rows->planned || rows->R == 0) return GRX_OK;
     return grx_launch_plan_kernel(ctx, rows->input_ids, rows->ids_stride, rows->R, rows->T, plan, stream);

@@ -114,8 +114,8 @@ typedef struct grx_rows {
     int64_t scores_stride;    /* elements                                           */
     int32_t V;
     int32_t dtype;            /* GRX_F32 / GRX_BF16 / GRX_F16                       */
-    int32_t planned;          /* 1: the row plans for exactly these rows are already in the
-                                 workspace (see grx_plan_request); 0: plan them now   */
+    int32_t planned;          /* 1: the kernel that produced exactly these rows has already
+                                 prepared this call (see grx_plan_request); 0: prepare it now */
     int32_t reserved;
 } grx_rows;
 
@@ -138,10 +138,11 @@ typedef struct grx_constraint {
 #define GRX_MAX_PENALTY_TOKENS 1536
 
 /* Bytes of device scratch the two calls below need for R rows (required when
- * R > 0).  It holds the per-row plans a small kernel writes ahead of the
- * streaming kernel (the trie node that governs each row), and the arrival
- * counters and partial (max, sum) pairs of rows that are streamed by several
- * workgroups (launches of few rows).  It must be 16-byte aligned and ZERO-FILLED
+ * R > 0).  It holds the per-row plans that a small kernel writes ahead of the
+ * streaming kernel in the fixed-hint mode (the trie node that governs each
+ * row; count-based calls walk their rows inside the streaming kernel), and the
+ * arrival counters and partial (max, sum) pairs of rows that are streamed by
+ * several workgroups (launches of few rows).  It must be 16-byte aligned and ZERO-FILLED
  * when first handed over; every call leaves the counters zero-filled again, so
  * one buffer serves all calls of a stream.  Calls that share a workspace must not
  * overlap. */
@@ -209,11 +210,15 @@ GRX_API int grx_timing_read(double* total_ms, int32_t* launches);
 
 /*
  * Planning ahead (no counterpart in the reference; used by the fused loop).  The
- * two calls above start with a small kernel that works out which trie node governs
- * every row.  The kernel that PRODUCES those rows can do that work instead:
- * grx_beam_step / grx_beam_init given a grx_plan_request write the plans of their
- * output rows (the running sequences, cur_len + 1 resp. prompt_len tokens each)
- * into `workspace`, and the next processor call on those rows passes
+ * two calls above start with a small kernel that prepares the call: in the
+ * fixed-hint mode it works out which trie node governs every row, in the
+ * count-based mode with prefix_ids it finds the lowest row that ends in them (the
+ * counter reset of logit_processor.py:39-40; the rows themselves are walked by the
+ * streaming kernel, and without prefix_ids there is no such kernel at all).  The
+ * kernel that PRODUCES the rows can do that work instead: grx_beam_step /
+ * grx_beam_init given a grx_plan_request prepare the call on their output rows
+ * (the running sequences, cur_len + 1 resp. prompt_len tokens each; row plans go
+ * into `workspace`), and the next processor call on those rows passes
  * grx_rows.planned = 1 with the same trie / state / constraint / workspace.
  * A plan made ahead may be dropped: a call that passes planned = 0 (other rows, or
  * the counter was set in between) plans for itself and first erases what the

@@ -300,9 +300,10 @@ def test_processors_drop_into_transformers_generate_on_the_gpu(kind):
 
 @pytest.mark.parametrize("kind", ["count", "count_none", "fixed"])
 def test_plans_written_by_the_beam_kernels_equal_the_planning_kernel(kind):
-    """Fused loop: beam init / beam step also write the row plans of the next processor call.
-    In lockstep with a second processor that plans for itself, the plan words in the two
-    workspaces and the candidates are identical at every step, over two generations."""
+    """Fused loop: beam init / beam step also prepare the next processor call (fixed-hint: the row
+    plans; count-based: the prefix_ids match reduction and the counter bookkeeping).  In lockstep with
+    a second processor that prepares for itself, the candidates -- and in the fixed-hint mode the plan
+    words in the two workspaces -- are identical at every step, over two generations."""
     from genrec_amd.beam import BeamSearchState
     from genrec_amd.fixed_hint_logit_processor import FixedHintConstrainedLogitsProcessor
     from genrec_amd.logit_processor import ConstrainedLogitsProcessor
@@ -345,10 +346,11 @@ def test_plans_written_by_the_beam_kernels_equal_the_planning_kernel(kind):
             assert ahead._planned is not None
             ahead.candidates_into(st_a.flat_running_sequences(), logits, cand_a)
             alone.candidates_into(st_b.flat_running_sequences(), logits, cand_b)
-            pa, pb = plans(ahead, B * K), plans(alone, B * K)
-            used = pb[:, 0] >= 0
-            assert torch.equal(pa[:, 0], pb[:, 0]) and torch.equal(pa[:, 3], pb[:, 3]), f"step {t}: nodes differ"
-            assert torch.equal(pa[used], pb[used]), f"step {t}: child ranges differ"
+            if kind == "fixed":  # count-based calls keep no row plans: their rows are walked by the streaming kernel
+                pa, pb = plans(ahead, B * K), plans(alone, B * K)
+                used = pb[:, 0] >= 0
+                assert torch.equal(pa[:, 0], pb[:, 0]), f"step {t}: nodes differ"
+                assert torch.equal(pa[used][:, :3], pb[used][:, :3]), f"step {t}: child ranges differ"
             assert torch.equal(cand_a.count, cand_b.count)
             valid = torch.arange(cand_a.cmax, device=dev)[None, :] < cand_a.count[:, None]
             assert torch.equal(cand_a.tokens[valid], cand_b.tokens[valid])
