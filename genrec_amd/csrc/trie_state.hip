@@ -1,5 +1,5 @@
-// Trie upload, device-resident processor state, and the per-row resolution of
-// the allowed-token node (integer work, one pass over the token rows).
+// Trie upload, device-resident processor state, and the preparation of a
+// processor call (integer work, one pass over the token rows).
 #include <stdarg.h>
 #include <string.h>
 
@@ -180,9 +180,11 @@ extern "C" int grx_state_read(grx_state* s, int32_t out[4], void* stream) {
     return GRX_OK;
 }
 
-// ------------------------------------------------------------- row plans ---
-// Which trie node governs each row, worked out ahead of the streaming kernel so
-// that kernel starts streaming after a single 16-byte load per row.
+// ------------------------------------------------------ call preparation ---
+// What has to be known about all rows before the streaming kernel starts: in the
+// fixed-hint mode the trie node that governs each row (found by a wave-wide scan of
+// the whole row), in the count-based mode only whether -- and from which row on --
+// the shared counter is reset.
 // Preparation of a count-based call whose rows nobody prepared ahead: the prefix_ids match
 // reduction and the once-per-call bookkeeping.  The rows themselves are walked by the
 // streaming kernel.
