@@ -546,7 +546,12 @@ __global__ __launch_bounds__(BS_THREADS) void beam_step_kernel(grx_beam_step_arg
             // reached without an EOS id) is rescanned the general way, one wave per row.
             __shared__ int s_pcode[MAXK];
             __shared__ unsigned char s_rescan[MAXK];
-            for (int k = tid; k < K; k += BS_THREADS) s_pcode[k] = plan_out[row0 + k].code;  // this call's plans
+            // This call's plans sit where the next call's are about to be written: a workgroup reads and
+            // then overwrites its own K entries.  A call on one row per group has its B plans spread over
+            // entries that OTHER workgroups overwrite, so there the parents' nodes are not used and every
+            // row takes the general scan (first step of a search only).
+            for (int k = tid; k < K; k += BS_THREADS)
+                s_pcode[k] = a.cand_shared ? GRX_RES_EMPTY : plan_out[row0 + k].code;
             __syncthreads();
             for (int k = tid; k < K; k += BS_THREADS) {
                 const int j = s_run_idx[k];

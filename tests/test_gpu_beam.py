@@ -596,3 +596,64 @@ def test_adversarial_score_layout_takes_the_general_selection_route(K, cmax):
         assert torch.equal(res.topk_parent.cpu().long()[live], tr.topk_parent[live])
         run_live = ref.running_beam_scores > LIVE
         assert torch.equal(st.running_sequences.cpu()[run_live], ref.running_sequences[run_live])
+
+
+def test_shared_first_step_with_hinted_prompts_in_the_fixed_hint_mode(tmp_path):
+    """Fixed-hint processor, prompts that already carry one ground-truth token (a different one per
+    group), first step on one row per group, on a dense trie where a token continues almost any
+    parent.  The plans of the B prompt rows and the plans the beam kernel writes for the B * K rows of
+    the next call share the front of one buffer, so the kernel must not look up a parent's node there;
+    entries a wrong lookup would hit are filled with a real but foreign node beforehand."""
+    from genrec_amd.beam import BeamSearchState
+    from genrec_amd.fixed_hint_logit_processor import FixedHintConstrainedLogitsProcessor
+    from genrec_amd.synth import ASSISTANT_PREFIX, SidTokenizer, synthetic_index, write_index
+    from genrec_amd.trie import build_trie_from_index, create_prefix_allowed_tokens_fn
+
+    dev = _dev()
+    path = write_index(str(tmp_path / "dense.index.json"), synthetic_index(300, 3, 8, seed=4))
+    tok = SidTokenizer.from_index(path)
+    trie, suffix, pidx = build_trie_from_index(path, tok, prefix=ASSISTANT_PREFIX)
+    fn = create_prefix_allowed_tokens_fn(trie, suffix)
+    V, eos, pad = tok.vocab_size_padded, tok.eos_token_id, tok.pad_token_id
+    K, B, steps = 8, 6, 3
+    items = sorted(trie)
+    firsts = sorted({it[len(suffix)] for it in items})
+    assert len(firsts) >= B
+    g = torch.Generator().manual_seed(3)
+    prompts = torch.tensor([[int(x) for x in torch.randint(100, 900, (4,), generator=g)] + list(suffix) + [firsts[b]]
+                            for b in range(B)])
+    rows = prompts.repeat_interleave(K, dim=0).to(dev)
+
+    one = FixedHintConstrainedLogitsProcessor(fn, K, pidx, suffix, eos, sync_errors=True)
+    full = FixedHintConstrainedLogitsProcessor(fn, K, pidx, suffix, eos, sync_errors=True)
+    L = rows.shape[1] + steps + 1
+    one._workspace(0, B * K)  # one buffer from the start, as a caller of the C ABI would hold it
+    st_one = BeamSearchState(rows, K, L, eos, pad, 1.0, False, planner=one, first_step_shared=True)
+    st_full = BeamSearchState(rows, K, L, eos, pad, 1.0, False, planner=full)
+    # entries B .. B*K of the plan buffer: the node of group 0's prompt, a valid parent for most tokens
+    ws = next(iter(one._workspaces.values()))
+    plan_off = 256 * 4 + 2048 * 8
+    plans = ws[plan_off : plan_off + 16 * B * K].view(torch.int32).view(B * K, 4)
+    torch.cuda.synchronize()
+    assert int(plans[0, 0]) > 0
+    plans[B:] = plans[0]
+    first = Candidates(B, trie.max_fanout, dev)
+    cand_one = Candidates(B * K, trie.max_fanout, dev)
+    cand_full = Candidates(B * K, trie.max_fanout, dev)
+    for t in range(steps):
+        if t == 0:
+            logits_b = (torch.randn(B, V, generator=g) * 3).to(dev)
+            one.candidates_into(st_one.prompt_rows(), logits_b, first, one_row_per_group=True)
+            full.candidates_into(st_full.flat_running_sequences(), logits_b.repeat_interleave(K, dim=0), cand_full)
+            st_one.step(first, V, planner=one, shared_rows=True)
+        else:
+            logits = (torch.randn(B * K, V, generator=g) * 3).to(dev)
+            one.candidates_into(st_one.flat_running_sequences(), logits, cand_one)
+            full.candidates_into(st_full.flat_running_sequences(), logits, cand_full)
+            valid = torch.arange(cand_full.cmax, device=dev)[None, :] < cand_full.count[:, None]
+            assert torch.equal(cand_one.count, cand_full.count), f"step {t}: allowed sets differ"
+            assert torch.equal(cand_one.tokens[valid], cand_full.tokens[valid])
+            st_one.step(cand_one, V, planner=one)
+        st_full.step(cand_full, V, planner=full)
+        assert torch.equal(st_one.running_sequences, st_full.running_sequences)
+    one._planned = full._planned = None
