@@ -657,3 +657,43 @@ def test_shared_first_step_with_hinted_prompts_in_the_fixed_hint_mode(tmp_path):
         st_full.step(cand_full, V, planner=full)
         assert torch.equal(st_one.running_sequences, st_full.running_sequences)
     one._planned = full._planned = None
+
+
+@pytest.mark.parametrize("first_step_shared", [False, True])
+def test_evaluation_style_50_beams_with_repetition_penalty_reproduces_generate(first_step_shared):
+    """tests/golden/eval50.npz (generate() as evaluate.py drives it: prefix_ids=None, count reset by hand,
+    50 beams all returned, length_penalty 0, repetition_penalty 1.1 from transformers' own processor):
+    the fused loop with the penalty folded into the streaming kernel returns the same item rankings
+    (bit-exact sequences and beam parents) and scores within 2e-5, two batches on one processor."""
+    from genrec_amd.beam import constrained_beam_search
+    from genrec_amd.logit_processor import ConstrainedLogitsProcessor
+    from genrec_amd.trie import FlatTrie, create_prefix_allowed_tokens_fn
+
+    dev = _dev()
+    data, meta = load_npz("eval50.npz")
+    prefix, eos, pad, K = meta["prefix"], meta["eos"], meta["pad"], meta["K"]
+    trie = FlatTrie(data["trie_sequences"].tolist())
+    fn = create_prefix_allowed_tokens_fn(trie, prefix)
+    proc = ConstrainedLogitsProcessor(fn, K, 3, None, eos, repetition_penalty=meta["repetition_penalty"])
+    for batch in meta["batches"]:
+        name = batch["name"]
+        prompts = torch.from_numpy(data[f"{name}.prompts"]).to(dev)
+        logits = [torch.from_numpy(data[f"{name}.logits.{t}"]).to(dev) for t in range(batch["steps"])]
+
+        def logits_fn(step, flat, next_parent):
+            if step == 0 and first_step_shared:
+                return logits[0][::K].contiguous()
+            return logits[step]
+
+        # constrained_beam_search resets the processor itself, which is evaluate.py's `count = 0`
+        _, seqs, scores, bidx = constrained_beam_search(
+            logits_fn, proc, prompts, K, batch["max_new_tokens"], eos, pad, meta["length_penalty"], False,
+            first_step_shared=first_step_shared)
+        want_scores = data[f"{name}.sequences_scores"]
+        live = want_scores > LIVE
+        assert int(live.sum()) == batch["live"]
+        assert np.array_equal(seqs.cpu().numpy()[live], data[f"{name}.sequences"][live])
+        assert np.array_equal(bidx.cpu().numpy()[live], data[f"{name}.beam_indices"][live])
+        assert np.max(np.abs(scores.cpu().numpy()[live] - want_scores[live])) <= 2e-5
+        assert proc.count == batch["steps"]
+    proc.check_errors()

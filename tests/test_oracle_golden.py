@@ -287,3 +287,34 @@ def test_beam_oracle_reproduces_generate_on_a_ragged_trie_in_every_stopping_mode
         assert torch.equal(scores_o[live], want_scores[live]), name
         assert torch.equal(seqs_o[:, :w][live], want_seqs[:, :w][live]), name
         assert torch.equal(bidx_o[:, :bw].long()[live], want_bidx[:, :bw].long()[live]), name
+
+
+def test_oracle_reproduces_evaluation_style_generate_with_50_beams_and_repetition_penalty():
+    """tests/golden/eval50.npz: generate() as evaluate.py drives it (count processor with prefix_ids=None,
+    count reset by hand per batch, 50 beams, length_penalty 0, repetition_penalty 1.1 applied by
+    transformers ahead of the reference processor), two batches with one processor object."""
+    from helpers import load_npz
+
+    data, meta = load_npz("eval50.npz")
+    prefix, eos, pad, K = meta["prefix"], meta["eos"], meta["pad"], meta["K"]
+    seqs = data["trie_sequences"].tolist()
+    inner = oproc.RefConstrainedLogitsProcessor(oproc.DictTrie(seqs).get, K, 3, None, eos)
+
+    def chain(ids, scores):
+        return inner(ids, oproc.ref_repetition_penalty(ids, scores, meta["repetition_penalty"]))
+
+    for batch in meta["batches"]:
+        name = batch["name"]
+        prompts = torch.from_numpy(data[f"{name}.prompts"])
+        logits = [torch.from_numpy(data[f"{name}.logits.{t}"]) for t in range(batch["steps"])]
+        inner.count = 0
+        state, _ = obeam.ref_constrained_beam_search(lambda step, flat: logits[step], chain, prompts, K,
+                                                     batch["max_new_tokens"], eos, pad, meta["length_penalty"], False)
+        seqs_o, scores_o, bidx_o = state.finalize()
+        want_scores = torch.from_numpy(data[f"{name}.sequences_scores"])
+        live = want_scores > -1.0e8
+        assert int(live.sum()) == batch["live"]
+        assert float((scores_o[live] - want_scores[live]).abs().max()) <= 2e-5  # fp32 sums of 5 log-probs
+        assert torch.equal(seqs_o[live], torch.from_numpy(data[f"{name}.sequences"])[live])
+        assert torch.equal(bidx_o.long()[live], torch.from_numpy(data[f"{name}.beam_indices"]).long()[live])
+        assert inner.count == batch["steps"]
