@@ -231,6 +231,33 @@ def time_processor_surface(args, wl, device, calls=10):
     return out
 
 
+def time_read_probe(wl, device, launches=20):
+    """Read-only pass over one of the logit buffers with the streaming kernel's access pattern
+    (grx_read_probe): the throughput this GPU gives that pattern, timed by the same dispatch events."""
+    import ctypes as C
+
+    import torch
+
+    from genrec_amd import _lib
+
+    lib = _lib.lib()
+    x = wl["logits"][min(1, len(wl["logits"]) - 1)]
+    R, row_bytes = x.shape[0], x.shape[1] * x.element_size()
+    out = torch.empty(R * 4, dtype=torch.int32, device=device)
+    stream = _lib.current_stream_ptr(device)
+    for i in range(launches + 2):
+        if i == 2:
+            torch.cuda.synchronize()
+            lib.grx_timing_enable(1)
+        _lib.check(lib.grx_read_probe(x.data_ptr(), x.stride(0) * x.element_size(), R, row_bytes, out.data_ptr(), stream))
+    torch.cuda.synchronize()
+    tot, n = C.c_double(), C.c_int32()
+    _lib.check(lib.grx_timing_read(C.byref(tot), C.byref(n)))
+    lib.grx_timing_enable(0)
+    ms = tot.value / max(n.value, 1)
+    return {"ms": ms, "GBps": R * row_bytes / ms / 1e6, "launches": n.value}
+
+
 def recorded_traffic(args, alg_bytes):
     """HBM bytes per launch of the dominant kernel from hardware counters.
 
@@ -352,6 +379,7 @@ def main() -> None:
         alg_bytes = R * wl["V"] * esize
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
         traffic, traffic_source = recorded_traffic(args, alg_bytes)
+        probe = time_read_probe(wl, device)
         out = {
             "metric": "constrained decode steps/sec (batch x beam = 8192, V ~ 152k)",
             "value": world * args.steps / elapsed,
@@ -389,6 +417,9 @@ def main() -> None:
                 "kernel_ms": kernel_ms,
                 "launches_timed": n.value,
                 "timed_every": max(1, args.time_every),
+                # the same rows read by a kernel that only loads them (same access pattern): what the part offers
+                "read_probe": probe,
+                "frac_of_read_probe": achieved / probe["GBps"] if probe["GBps"] else None,
             },
         }
         if world == 1 and not args.no_processor_surface:

@@ -39,6 +39,7 @@ EXPORTED_SYMBOLS = (
     "grx_candidate_stride",
     "grx_timing_enable",
     "grx_timing_read",
+    "grx_read_probe",
     "grx_beam_step",
     "grx_beam_init",
     "grx_sid_rewards",
@@ -199,6 +200,8 @@ def _declare(lib: C.CDLL) -> None:
     lib.grx_timing_enable.argtypes = [C.c_int]
     lib.grx_timing_read.restype = C.c_int
     lib.grx_timing_read.argtypes = [C.POINTER(C.c_double), C.POINTER(i32)]
+    lib.grx_read_probe.restype = C.c_int
+    lib.grx_read_probe.argtypes = [vp, i64, i32, i64, vp, vp]
     lib.grx_beam_step.restype = C.c_int
     lib.grx_beam_step.argtypes = [C.POINTER(GrxBeamStepArgs), vp]
     lib.grx_beam_init.restype = C.c_int

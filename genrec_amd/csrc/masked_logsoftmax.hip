@@ -187,34 +187,49 @@ __device__ __forceinline__ auto to_out(float v) {
 }
 
 // ---- online softmax accumulator ---------------------------------------------
+// A thread's share of a row: m = largest element seen, s = sum of 2^(x * log2e + c) over the
+// elements seen, c = -(m * log2e) as rounded when m last changed (0 while nothing finite was seen).
+// exp(x - m) is evaluated as exp2(fma(x, log2e, c)): one fused multiply-add per element, two
+// elements per instruction (packed fp32 math).  Keeping c itself -- instead of recomputing the
+// offset from m -- makes the rescale factor of an unchanged maximum exactly 1; recomputing it
+// drifts by the rounding residual of m * log2e once per batch of elements.
 struct MaxSum {
-    float m, s;
+    float m, s, c;
 };
 
 template <int N>
 __device__ __forceinline__ void accumulate(MaxSum& a, const float* v) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
     float cm = v[0];
 #pragma unroll
     for (int j = 1; j < N; ++j) cm = fmaxf(cm, v[j]);
     const float mn = fmaxf(a.m, cm);
-    const float mref = (mn == -INFINITY) ? 0.f : mn;
+    const float c = (mn == -INFINITY) ? 0.f : -mn * kLog2e;
+    const f32x2 L2 = {kLog2e, kLog2e}, C2 = {c, c};
     float acc0 = 0.f, acc1 = 0.f;
 #pragma unroll
     for (int j = 0; j + 1 < N; j += 2) {
-        acc0 += fast_exp2((v[j] - mref) * kLog2e);
-        acc1 += fast_exp2((v[j + 1] - mref) * kLog2e);
+        const f32x2 x = {v[j], v[j + 1]};
+        const f32x2 t = __builtin_elementwise_fma(x, L2, C2);
+        acc0 += fast_exp2(t.x);
+        acc1 += fast_exp2(t.y);
     }
-    if (N & 1) acc0 += fast_exp2((v[N - 1] - mref) * kLog2e);
-    a.s = a.s * fast_exp2((a.m - mref) * kLog2e) + (acc0 + acc1);
+    if (N & 1) acc0 += fast_exp2(fmaf(v[N - 1], kLog2e, c));
+    // c <= a.c whenever a.s > 0 (the maximum only grows), so the factor is in (0, 1]; a sum that is
+    // still empty has no offset yet and must not meet 2^(c - 0), which overflows for c > 128
+    a.s = (a.s > 0.f ? a.s * fast_exp2(c - a.c) : 0.f) + (acc0 + acc1);
     a.m = mn;
+    a.c = c;
 }
 
+// Workgroup total as (m, s) with s = sum of exp(x - m): the threads' sums are brought to the
+// offset of the workgroup maximum, and the rounding residual of that offset is taken out at the end.
 __device__ __forceinline__ MaxSum block_combine(MaxSum a, float* s_m, float* s_s) {
     const int lane = threadIdx.x & (GRX_WAVE - 1);
     const int wave = threadIdx.x / GRX_WAVE;
-    float M = wave_max(a.m);
-    float Mref = (M == -INFINITY) ? 0.f : M;
-    float S = wave_sum(a.s * fast_exp2((a.m - Mref) * kLog2e));
+    const float M = wave_max(a.m);
+    const float C = (M == -INFINITY) ? 0.f : -M * kLog2e;
+    const float S = wave_sum(a.s > 0.f ? a.s * fast_exp2(C - a.c) : 0.f);
     if (lane == 0) {
         s_m[wave] = M;
         s_s[wave] = S;
@@ -223,13 +238,18 @@ __device__ __forceinline__ MaxSum block_combine(MaxSum a, float* s_m, float* s_s
     float bm = s_m[0];
 #pragma unroll
     for (int w = 1; w < MLS_WAVES; ++w) bm = fmaxf(bm, s_m[w]);
-    const float bref = (bm == -INFINITY) ? 0.f : bm;
+    const float bc = (bm == -INFINITY) ? 0.f : -bm * kLog2e;
     float bs = 0.f;
 #pragma unroll
-    for (int w = 0; w < MLS_WAVES; ++w) bs += s_s[w] * fast_exp2((s_m[w] - bref) * kLog2e);
+    for (int w = 0; w < MLS_WAVES; ++w) {
+        const float wc = (s_m[w] == -INFINITY) ? 0.f : -s_m[w] * kLog2e;  // the offset that wave summed at
+        bs += s_s[w] > 0.f ? s_s[w] * fast_exp2(bc - wc) : 0.f;
+    }
     MaxSum r;
     r.m = bm;
-    r.s = bs;
+    // bs = sum 2^(x * log2e + bc); with m * log2e + bc = residual, sum exp(x - m) = bs * 2^(-residual)
+    r.s = (bm == -INFINITY) ? bs : bs * fast_exp2(-fmaf(bm, kLog2e, bc));
+    r.c = bc;
     return r;
 }
 
@@ -333,6 +353,7 @@ __global__ __launch_bounds__(MLS_THREADS) void masked_lsm_kernel(MlsArgs a) {
     MaxSum acc;
     acc.m = -INFINITY;
     acc.s = 0.f;
+    acc.c = 0.f;
 
     if (VEC) {
         // The dense output of a vectorised launch was filled with -inf by
@@ -633,6 +654,54 @@ static int timing_slot() {
         ++g_ev_created;
     }
     return g_timing_n;
+}
+
+// ---- read probe ---------------------------------------------------------------
+// The streaming kernel's access pattern with everything else taken away: one workgroup per row,
+// MLS_UNROLL 16-byte non-temporal loads in flight per thread, the loaded words folded into one
+// checksum word per wave.  What this reaches is the read throughput the part gives this pattern.
+__global__ __launch_bounds__(MLS_THREADS) void read_probe_kernel(const char* base, int64_t stride_bytes, int nvec,
+                                                                 uint32_t* __restrict__ out) {
+    const int tid = threadIdx.x;
+    const RowStream vp(base + (int64_t)blockIdx.x * stride_bytes, (int64_t)nvec * 16);
+    uint32_t acc = 0;
+    int i = tid;
+    for (; i + (MLS_UNROLL - 1) * MLS_THREADS < nvec; i += MLS_UNROLL * MLS_THREADS) {
+        u32x4 v[MLS_UNROLL];
+#pragma unroll
+        for (int u = 0; u < MLS_UNROLL; ++u) v[u] = vp.load(i + u * MLS_THREADS);
+#pragma unroll
+        for (int u = 0; u < MLS_UNROLL; ++u) acc ^= v[u].x ^ v[u].y ^ v[u].z ^ v[u].w;
+    }
+    for (; i < nvec; i += MLS_THREADS) {
+        const u32x4 v = vp.load(i);
+        acc ^= v.x ^ v.y ^ v.z ^ v.w;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc ^= __shfl_xor(acc, o, GRX_WAVE);
+    if ((tid & (GRX_WAVE - 1)) == 0) out[(int64_t)blockIdx.x * MLS_WAVES + tid / GRX_WAVE] = acc;
+}
+
+extern "C" int grx_read_probe(const void* rows, int64_t stride_bytes, int32_t R, int64_t row_bytes, uint32_t* out,
+                              void* stream) {
+    const char* who = "grx_read_probe";
+    GRX_REQUIRE(R >= 0 && row_bytes >= 0 && stride_bytes >= row_bytes, GRX_E_INVALID, "%s: bad shape", who);
+    if (R == 0) return GRX_OK;
+    GRX_REQUIRE(rows != nullptr && out != nullptr, GRX_E_INVALID, "%s: null pointer", who);
+    GRX_REQUIRE(((uintptr_t)rows & 15u) == 0 && (stride_bytes & 15) == 0, GRX_E_INVALID,
+                "%s: rows must be 16-byte aligned", who);
+    GRX_REQUIRE(row_bytes / 16 <= 0x7FFFFFFF, GRX_E_UNSUPPORTED, "%s: row too long", who);
+    const int slot = timing_slot();
+    hipEvent_t ev0 = slot >= 0 ? g_ev_start[slot] : nullptr, ev1 = slot >= 0 ? g_ev_stop[slot] : nullptr;
+    if (ev0)
+        hipExtLaunchKernelGGL(read_probe_kernel, dim3((unsigned)R), dim3(MLS_THREADS), 0, (hipStream_t)stream, ev0, ev1, 0,
+                              (const char*)rows, stride_bytes, (int)(row_bytes / 16), out);
+    else
+        hipLaunchKernelGGL(read_probe_kernel, dim3((unsigned)R), dim3(MLS_THREADS), 0, (hipStream_t)stream,
+                           (const char*)rows, stride_bytes, (int)(row_bytes / 16), out);
+    GRX_CHECK_HIP(hipGetLastError());
+    if (slot >= 0) g_timing_n = slot + 1;
+    return GRX_OK;
 }
 
 // ---- launch -------------------------------------------------------------------

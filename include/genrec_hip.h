@@ -209,6 +209,18 @@ GRX_API int grx_timing_enable(int every);
 GRX_API int grx_timing_read(double* total_ms, int32_t* launches);
 
 /*
+ * Read probe for benchmarks (no counterpart in the reference): streams R rows of
+ * row_bytes bytes (device, 16-byte aligned, row stride stride_bytes) with the
+ * streaming kernel's access pattern -- one workgroup per row, the same 16-byte
+ * non-temporal loads -- and nothing else; out (device uint32 [R * 4]) receives a
+ * checksum word per wave.  Its throughput is the ceiling this GPU offers that
+ * pattern, which puts the streaming kernel's figure in proportion.  Timed like
+ * the calls above while timing is enabled.
+ */
+GRX_API int grx_read_probe(const void* rows, int64_t stride_bytes, int32_t R, int64_t row_bytes, uint32_t* out,
+                           void* stream);
+
+/*
  * Planning ahead (no counterpart in the reference; used by the fused loop).  The
  * two calls above start with a small kernel that prepares the call: in the
  * fixed-hint mode it works out which trie node governs every row, in the
