@@ -72,6 +72,12 @@ def main():
         f"correction) + write {write / 1e6:.2f} MB per launch vs {alg / 1e9:.4f} GB algorithmic -> ratio "
         f"{(fetch + write) / alg:.4f}",
     ]
+    if rf.get("read_probe"):
+        rp = rf["read_probe"]
+        lines.append(f"* read probe (the same rows read by a kernel that only loads them, same access pattern, "
+                     f"{rp['launches']} launches): {rp['ms'] * 1e3:.1f} µs = {rp['GBps']:.0f} GB/s = "
+                     f"{rp['GBps'] / 80:.1f} % of peak; the streaming kernel reaches "
+                     f"{rf['frac_of_read_probe'] * 100:.1f} % of that")
     if cb:
         lines.append(f"* cpu_baseline ({cb['kind']}, {cb['cores']} threads): {cb['value']:.3f} steps/s ({cb['sample']})")
     if ps:
