@@ -74,6 +74,8 @@ class GrxConstraint(C.Structure):
         ("prefix_ids", C.c_int64 * GRX_MAX_PREFIX),
         ("repetition_penalty", C.c_float),
         ("penalty_skip", C.c_int32),
+        ("assume_normalized", C.c_int32),
+        ("reserved", C.c_int32),
     ]
 
 

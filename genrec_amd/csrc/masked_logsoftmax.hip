@@ -59,6 +59,7 @@ struct MlsArgs {
     int64_t ids_stride;
     int T;
     int S;
+    int skip_stream;       // rows are log-softmax values already (log-sum-exp 0): gather only
     int* split_count;      // [R] arrival counters, zero between calls
     float2* split_part;    // [R * S] partial (max, sum)
 };
@@ -292,7 +293,7 @@ __global__ __launch_bounds__(MLS_THREADS) void masked_lsm_kernel(MlsArgs a) {
     }
     const RowStream vp(row, (int64_t)nvec * 16);
     u32x4 v_head[MLS_UNROLL];
-    const bool head = VEC && (v_lo + tid + (MLS_UNROLL - 1) * MLS_THREADS < v_hi);
+    const bool head = VEC && !a.skip_stream && (v_lo + tid + (MLS_UNROLL - 1) * MLS_THREADS < v_hi);
     if (head) {
 #pragma unroll
         for (int u = 0; u < MLS_UNROLL; ++u) v_head[u] = vp.load(v_lo + tid + u * MLS_THREADS);
@@ -355,7 +356,7 @@ __global__ __launch_bounds__(MLS_THREADS) void masked_lsm_kernel(MlsArgs a) {
     acc.s = 0.f;
     acc.c = 0.f;
 
-    if (VEC) {
+    if (VEC && !a.skip_stream) {
         // The dense output of a vectorised launch was filled with -inf by
         // fill_rows_kernel beforehand (write-only and read-only traffic run
         // faster back to back than interleaved), so the stream only reads.
@@ -385,11 +386,11 @@ __global__ __launch_bounds__(MLS_THREADS) void masked_lsm_kernel(MlsArgs a) {
         }
     }
     // Elements not covered by 16-byte vectors (all of them when !VEC); the last part of a split row.
-    if (!SPLIT || part == a.S - 1) {
+    if ((!SPLIT || part == a.S - 1) && !(VEC && a.skip_stream)) {
         const float ninf_f = -INFINITY;
         for (int e = (VEC ? nvec * EPV : 0) + tid; e < a.V; e += MLS_THREADS) {
             float f[1] = {E::to_float(row[e])};
-            accumulate<1>(acc, f);
+            if (!a.skip_stream) accumulate<1>(acc, f);
             if (VEC) continue;  // pre-filled
             if (OUT == OUT_FULL_F32) {
                 reinterpret_cast<float*>(a.out)[(int64_t)r * a.out_stride + e] = ninf_f;
@@ -406,7 +407,14 @@ __global__ __launch_bounds__(MLS_THREADS) void masked_lsm_kernel(MlsArgs a) {
     }
     typedef typename std::conditional<OUT == OUT_FULL_F32, float, T>::type OT;
     MSTAMP(3);
-    MaxSum tot = block_combine(acc, s_m, s_s);  // contains a workgroup barrier
+    MaxSum tot;
+    if (a.skip_stream) {  // the caller's rows are normalised: max-shifted sum 1 at maximum 0, log-sum-exp 0
+        tot.m = 0.f;
+        tot.s = 1.f;
+        tot.c = 0.f;
+    } else {
+        tot = block_combine(acc, s_m, s_s);  // contains a workgroup barrier
+    }
     MSTAMP(4);
     if (SPLIT) {
         // Publish this part; the workgroup that observes the S-th arrival owns the row.
@@ -754,6 +762,10 @@ static int run_step(const char* who, const grx_trie* trie, grx_state* state, con
     GRX_REQUIRE(con->eos_token_id < rows->V, GRX_E_INVALID, "%s: eos_token_id %d outside V=%d", who,
                 con->eos_token_id, rows->V);
     const bool penalise = con->repetition_penalty != 0.f && con->repetition_penalty != 1.f;
+    GRX_REQUIRE(con->assume_normalized == 0 || con->assume_normalized == 1, GRX_E_INVALID,
+                "%s: assume_normalized must be 0 or 1", who);
+    GRX_REQUIRE(!(penalise && con->assume_normalized), GRX_E_UNSUPPORTED,
+                "%s: the fused repetition penalty needs the rows streamed (assume_normalized must be 0)", who);
     if (penalise) {
         GRX_REQUIRE(con->repetition_penalty > 0.f, GRX_E_INVALID, "%s: repetition_penalty must be positive", who);
         GRX_REQUIRE(con->penalty_skip >= 0, GRX_E_INVALID, "%s: penalty_skip must be >= 0", who);
@@ -789,7 +801,8 @@ static int run_step(const char* who, const grx_trie* trie, grx_state* state, con
     a.eos = con->eos_token_id;
     const bool vec = rows_16b_aligned(rows->scores, rows->scores_stride, dtype_size(rows->dtype)) && out_aligned;
     a.S = 1;
-    if (vec) {
+    a.skip_stream = con->assume_normalized;
+    if (vec && !a.skip_stream) {
         const int S = grx_split_factor(rows->R, (int)(rows->V / (16 / dtype_size(rows->dtype))));
         if (S > 1) {
             a.S = S;

@@ -107,6 +107,7 @@ class _TrieConstrainedBase(LogitsProcessor):
         sync_errors: Optional[bool] = None,
         repetition_penalty: float = 1.0,
         prompt_ignore_length: int = 0,
+        assume_normalized: bool = False,
     ):
         self._prefix_allowed_tokens_fn = prefix_allowed_tokens_fn
         self._num_beams = num_beams
@@ -122,6 +123,12 @@ class _TrieConstrainedBase(LogitsProcessor):
             raise ValueError(f"`penalty` has to be a strictly positive float, but is {repetition_penalty}")
         self.repetition_penalty = float(repetition_penalty)
         self.prompt_ignore_length = int(prompt_ignore_length or 0)
+        # Extension: the caller vouches that `scores` rows are log-softmax values already, as they are
+        # when generate() calls this processor with nothing ahead of it in the list (the reference's own
+        # log_softmax then moves values by < 1e-6).  The rows are not read: half the traffic per call.
+        self.assume_normalized = bool(assume_normalized)
+        if self.assume_normalized and self.repetition_penalty != 1.0:
+            raise ValueError("assume_normalized cannot be combined with the fused repetition penalty")
         self._trie: Optional[FlatTrie] = None
         self._states: dict[int, _DeviceState] = {}
         self._workspaces: dict[int, torch.Tensor] = {}
@@ -209,6 +216,7 @@ class _TrieConstrainedBase(LogitsProcessor):
         con.eos_token_id = -1 if self.eos_token_id is None else int(self.eos_token_id)
         con.repetition_penalty = self.repetition_penalty
         con.penalty_skip = self.prompt_ignore_length
+        con.assume_normalized = 1 if self.assume_normalized else 0
         return con
 
     def _rows(self, input_ids: torch.Tensor, scores: torch.Tensor, whole_groups: bool = True
@@ -403,10 +411,12 @@ class ConstrainedLogitsProcessor(_TrieConstrainedBase):
         sync_errors: Optional[bool] = None,
         repetition_penalty: float = 1.0,
         prompt_ignore_length: int = 0,
+        assume_normalized: bool = False,
     ):
         super().__init__(
             prefix_allowed_tokens_fn, num_beams, prefix_index, prefix_ids, eos_token_id, sync_errors=sync_errors,
             repetition_penalty=repetition_penalty, prompt_ignore_length=prompt_ignore_length,
+            assume_normalized=assume_normalized,
         )
         self.initial_count = int(initial_count)
         self._count_host = self.initial_count  # value to push to a device on first use / after a set

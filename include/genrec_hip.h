@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define GRX_ABI_VERSION 4
+#define GRX_ABI_VERSION 5
 
 #if defined(GRX_BUILDING)
 #define GRX_API __attribute__((visibility("default")))
@@ -134,6 +134,15 @@ typedef struct grx_constraint {
      * GRX_MAX_PENALTY_TOKENS tokens then. */
     float repetition_penalty;
     int32_t penalty_skip;     /* prompt_ignore_length of the HF processor; 0 = none  */
+    /* 1: the caller vouches that every row of `scores` already is a log-softmax
+     * (log-sum-exp 0), which is what generate() hands a processor when nothing ran
+     * before it (generation/utils.py:3388-3389; the reference's second log_softmax,
+     * logit_processor.py:30, then changes values by < 1e-6).  The rows are not
+     * streamed: allowed positions receive scores[r, v] as is, the dense output costs
+     * one write pass instead of a read and a write.  Not combinable with the fused
+     * repetition penalty. */
+    int32_t assume_normalized;
+    int32_t reserved;
 } grx_constraint;
 #define GRX_MAX_PENALTY_TOKENS 1536
 

@@ -699,3 +699,35 @@ def test_step_entry_points_reject_bad_operands_before_launching():
     torch.cuda.synchronize()
     assert not bool(cand.any()), "a refused call must not have written anything"
     assert proc._read_state(0)[3] == calls_before, "a refused call must not count as a processor call"
+
+
+@pytest.mark.parametrize("case", ["count_rl", "count_eval", "fixed_hint"])
+def test_rows_that_are_already_normalised_need_not_be_streamed(case):
+    """``assume_normalized=True``: generate() hands a processor log_softmax(logits) when nothing runs
+    ahead of it, so the reference's own log_softmax is a near-identity (< 1e-6).  The kernel then skips
+    the read pass: allowed positions carry the input value bit for bit, everything else is -inf, and the
+    result is within the usual 1e-5 of the reference output recorded for the raw scores."""
+    data, meta, trie, fn = _small_setup()
+    dev = _dev()
+    proc = _make(case, fn, meta, assume_normalized=True)
+    info = meta["cases"][case]
+    for i in range(info["steps"]):
+        ids = torch.from_numpy(data[f"{case}.ids.{i}"]).to(dev)
+        raw = torch.from_numpy(data[f"{case}.scores.{i}"]).to(dev)
+        logp = torch.log_softmax(raw, dim=-1)
+        out = proc(ids, logp)
+        want = data[f"{case}.out.{i}"]
+        _assert_dense_close(out, want, FP32_TOL)
+        fin = torch.isfinite(out)
+        assert torch.equal(out[fin], logp[fin])  # passed through untouched
+        if info["counts_after"][i] >= 0:
+            assert proc.count == info["counts_after"][i]
+            proc.count = proc.count - 1
+        cand = proc.candidates(ids, logp)
+        valid = torch.arange(cand.cmax, device=dev)[None, :] < cand.count[:, None]
+        assert torch.equal(cand.count.long(), fin.sum(dim=1))
+        assert torch.equal(cand.logp[valid], logp[fin])
+        assert bool((cand.logsumexp == 0).all())
+    proc.check_errors()
+    with pytest.raises(ValueError, match="assume_normalized"):
+        _make(case, fn, meta, assume_normalized=True, repetition_penalty=1.1)

@@ -82,7 +82,7 @@ def main():
         lines.append(f"* cpu_baseline ({cb['kind']}, {cb['cores']} threads): {cb['value']:.3f} steps/s ({cb['sample']})")
     if ps:
         for k, v in ps.items():
-            lines.append(f"* processor surface {k} (dense [R, V] output, fill + stream): {v['ms_per_call'] * 1e3:.0f} µs "
+            lines.append(f"* processor surface {k} (dense [R, V] output): {v['ms_per_call'] * 1e3:.0f} µs "
                          f"per call = {v['achieved_GBps']:.0f} GB/s = {v['frac_of_peak'] * 100:.1f} % of peak on "
                          f"{v['algorithmic_bytes'] / 1e9:.1f} GB")
     lines += ["", "`rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --no-processor-surface` "
