@@ -217,12 +217,15 @@ def test_fused_loop_on_a_ragged_trie_in_every_stopping_mode():
         assert float((got_scores[live] - want_scores[live]).abs().max()) <= SCORE_TOL, name
 
 
+@pytest.mark.parametrize("vouched", [False, True])
 @pytest.mark.parametrize("kind", ["count", "fixed"])
-def test_processors_drop_into_transformers_generate_on_the_gpu(kind):
+def test_processors_drop_into_transformers_generate_on_the_gpu(kind, vouched):
     """The unmodified HF loop on cuda:0 (tiny random Qwen2) with our processor in its
     LogitsProcessorList, as evaluate.py:363-371 / MIMIGenRec.py:79 call it, against the same loop with
     the CPU restatement of the reference processor: same sequences and beam indices, scores within
-    1e-5, over two consecutive generate() calls (counter reset between them as evaluate.py:358-361 does)."""
+    1e-5, over two consecutive generate() calls (counter reset between them as evaluate.py:358-361 does).
+    ``vouched``: with ``assume_normalized=True`` -- generate() hands the lone processor log-softmax values,
+    so skipping the read pass must give the same beams."""
     from transformers import LogitsProcessor, LogitsProcessorList, Qwen2Config, Qwen2ForCausalLM
 
     from oracle.processors import (DictTrie, RefConstrainedLogitsProcessor,
@@ -267,10 +270,10 @@ def test_processors_drop_into_transformers_generate_on_the_gpu(kind):
 
     get = DictTrie(seqs).get
     if kind == "count":
-        ours = ConstrainedLogitsProcessor(fn, K, 3, None, eos)           # evaluate.py:283-288 passes no prefix_ids
+        ours = ConstrainedLogitsProcessor(fn, K, 3, None, eos, assume_normalized=vouched)  # evaluate.py:283-288: no prefix_ids
         ref = OnCpu(RefConstrainedLogitsProcessor(get, K, 3, None, eos))
     else:
-        ours = FixedHintConstrainedLogitsProcessor(fn, K, 3, prefix, eos)
+        ours = FixedHintConstrainedLogitsProcessor(fn, K, 3, prefix, eos, assume_normalized=vouched)
         ref = OnCpu(RefFixedHintConstrainedLogitsProcessor(get, K, 3, prefix, eos))
     g = torch.Generator().manual_seed(3)
     for round_ in range(2):
