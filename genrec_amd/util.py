@@ -38,7 +38,8 @@ def print_main_process(*args: Any, **kwargs: Any) -> None:
         print(*args, **kwargs)
 
 
-def _build(cls, label: str, index_path: str, tokenizer, prefix, num_beams: int, sid_levels: int) -> LogitsProcessorList:
+def _build(cls, label: str, index_path: str, tokenizer, prefix, num_beams: int, sid_levels: int,
+           **processor_options) -> LogitsProcessorList:
     print_main_process(f"Building {label}Trie from {index_path}...")
     trie, prompt_suffix_ids, prefix_index = build_trie_from_index(
         index_path, tokenizer, prefix=prefix, sid_levels=sid_levels
@@ -53,22 +54,26 @@ def _build(cls, label: str, index_path: str, tokenizer, prefix, num_beams: int, 
                 prefix_index=prefix_index,
                 prefix_ids=prompt_suffix_ids,
                 eos_token_id=tokenizer.eos_token_id,
+                **processor_options,
             )
         ]
     )
 
 
 def build_constrained_logits_processor(index_path: str, tokenizer, prefix: Optional[str] = None, num_beams: int = 50,
-                                       sid_levels: int = -1) -> LogitsProcessorList:
-    """Trie from the index + count-based processor in a ``LogitsProcessorList``."""
-    return _build(ConstrainedLogitsProcessor, "", index_path, tokenizer, prefix, num_beams, sid_levels)
+                                       sid_levels: int = -1, **processor_options) -> LogitsProcessorList:
+    """Trie from the index + count-based processor in a ``LogitsProcessorList`` (reference signature;
+    ``processor_options`` are this package's keyword-only extras, e.g. ``assume_normalized=True``)."""
+    return _build(ConstrainedLogitsProcessor, "", index_path, tokenizer, prefix, num_beams, sid_levels,
+                  **processor_options)
 
 
 def build_fixed_hint_constrained_logits_processor(index_path: str, tokenizer, prefix: Optional[str] = None,
-                                                  num_beams: int = 50, sid_levels: int = -1) -> LogitsProcessorList:
+                                                  num_beams: int = 50, sid_levels: int = -1,
+                                                  **processor_options) -> LogitsProcessorList:
     """Trie from the index + fixed-hint processor in a ``LogitsProcessorList``."""
     return _build(FixedHintConstrainedLogitsProcessor, "FixedHint ", index_path, tokenizer, prefix, num_beams,
-                  sid_levels)
+                  sid_levels, **processor_options)
 
 
 def _extract_number(text: str) -> list[int]:
