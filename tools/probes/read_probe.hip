@@ -26,6 +26,23 @@ __global__ __launch_bounds__(T) void by_row(const u32x4* p, int64_t row_vecs, ui
     for (; i < row_vecs; i += T) acc ^= fold(__builtin_nontemporal_load(r + i));
     finish(acc, out);
 }
+// (1b) one WAVE per row: a workgroup of 4 waves holds 4 rows, no cross-wave work at all
+template <int UU>
+__global__ __launch_bounds__(T) void by_row_wave(const u32x4* p, int64_t row_vecs, uint32_t* out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const u32x4* r = p + ((int64_t)blockIdx.x * (T / 64) + wave) * row_vecs;
+    uint32_t acc = 0;
+    int64_t i = lane;
+    for (; i + (UU - 1) * 64 < row_vecs; i += UU * 64) {
+        u32x4 v[UU];
+#pragma unroll
+        for (int u = 0; u < UU; ++u) v[u] = __builtin_nontemporal_load(r + i + u * 64);
+#pragma unroll
+        for (int u = 0; u < UU; ++u) acc ^= fold(v[u]);
+    }
+    for (; i < row_vecs; i += 64) acc ^= fold(__builtin_nontemporal_load(r + i));
+    finish(acc, out);
+}
 // (2) flat sweep: workgroup b reads chunk b (CH vectors) of the whole buffer
 template <int CH>
 __global__ __launch_bounds__(T) void by_chunk(const u32x4* p, int64_t total_vecs, uint32_t* out) {
@@ -82,6 +99,8 @@ int main() {
     hipMalloc(&out, 4 * 1024 * 1024 * 4);
     const double bytes = (double)total * 16;
     timeit("one workgroup per row (305 KB each)", bytes, [&] { by_row<<<R, T>>>(p, row_vecs, out); });
+    timeit("one wave per row, 4 loads in flight", bytes, [&] { by_row_wave<4><<<R / 4, T>>>(p, row_vecs, out); });
+    timeit("one wave per row, 8 loads in flight", bytes, [&] { by_row_wave<8><<<R / 4, T>>>(p, row_vecs, out); });
     timeit("flat sweep, 16 KB chunk per workgroup", bytes, [&] { by_chunk<1024><<<(total + 1023) / 1024, T>>>(p, total, out); });
     timeit("flat sweep, 64 KB chunk per workgroup", bytes, [&] { by_chunk<4096><<<(total + 4095) / 4096, T>>>(p, total, out); });
     timeit("flat sweep, 256 KB chunk per workgroup", bytes, [&] { by_chunk<16384><<<(total + 16383) / 16384, T>>>(p, total, out); });
