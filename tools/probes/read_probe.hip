@@ -43,6 +43,24 @@ __global__ __launch_bounds__(T) void by_row_wave(const u32x4* p, int64_t row_vec
     for (; i < row_vecs; i += 64) acc ^= fold(__builtin_nontemporal_load(r + i));
     finish(acc, out);
 }
+// (1c) one workgroup per row with the trip count known at compile time (fully unrolled)
+template <int ROW_VECS>
+__global__ __launch_bounds__(T) void by_row_static(const u32x4* p, uint32_t* out) {
+    const u32x4* r = p + (int64_t)blockIdx.x * ROW_VECS;
+    uint32_t acc = 0;
+#pragma unroll
+    for (int j = 0; j < (ROW_VECS + U * T - 1) / (U * T); ++j) {
+        u32x4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = (j * U + u) * T + threadIdx.x;
+            v[u] = i < ROW_VECS ? __builtin_nontemporal_load(r + i) : u32x4{0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc ^= fold(v[u]);
+    }
+    finish(acc, out);
+}
 // (2) flat sweep: workgroup b reads chunk b (CH vectors) of the whole buffer
 template <int CH>
 __global__ __launch_bounds__(T) void by_chunk(const u32x4* p, int64_t total_vecs, uint32_t* out) {
@@ -99,6 +117,8 @@ int main() {
     hipMalloc(&out, 4 * 1024 * 1024 * 4);
     const double bytes = (double)total * 16;
     timeit("one workgroup per row (305 KB each)", bytes, [&] { by_row<<<R, T>>>(p, row_vecs, out); });
+    timeit("one workgroup per row, static trip count", bytes, [&] { by_row_static<19080><<<R, T>>>(p, out); });
+    timeit("one workgroup per 256 KB 'row' (dynamic loop)", bytes, [&] { by_row<<<total / 16384, T>>>(p, 16384, out); });
     timeit("one wave per row, 4 loads in flight", bytes, [&] { by_row_wave<4><<<R / 4, T>>>(p, row_vecs, out); });
     timeit("one wave per row, 8 loads in flight", bytes, [&] { by_row_wave<8><<<R / 4, T>>>(p, row_vecs, out); });
     timeit("flat sweep, 16 KB chunk per workgroup", bytes, [&] { by_chunk<1024><<<(total + 1023) / 1024, T>>>(p, total, out); });
