@@ -393,6 +393,30 @@ __global__ __launch_bounds__(BS_THREADS) void beam_step_kernel(grx_beam_step_arg
             }
             if (lane < n && rank < K) (wave == 0 ? s_run_idx : s_fin_idx)[rank] = lane;
         }
+    } else if (n_keep + n_merged <= SURV_CAP) {
+        // Larger lists: (score descending, index ascending) becomes one unique 64-bit key per element --
+        // kept in the survivor buffer, which is free by now -- and the rank of an element is the number
+        // of larger keys: one 64-bit compare per pair instead of three compares and their logic.
+        unsigned long long* const rkey = s_surv;
+        unsigned long long* const mkey = s_surv + n_keep;
+        for (int j = tid; j < n_keep + n_merged; j += BS_THREADS) {
+            const bool running = j < n_keep;
+            const int i = running ? j : j - n_keep;
+            s_surv[j] = ((unsigned long long)float_to_ordered(running ? s_rs[i] : s_merged[i]) << 32) |
+                        (unsigned long long)(0xFFFFFFFFu - (uint32_t)i);
+        }
+        __syncthreads();
+        for (int idx = tid; idx < n_keep + n_merged; idx += BS_THREADS) {  // both lists at once
+            const bool running = idx < n_keep;
+            const unsigned long long* __restrict__ keys = running ? rkey : mkey;
+            const int n = running ? n_keep : n_merged;
+            const int j = running ? idx : idx - n_keep;
+            const unsigned long long mine = keys[j];
+            int rank = 0;
+#pragma unroll 8
+            for (int i = 0; i < n; ++i) rank += keys[i] > mine ? 1 : 0;
+            if (rank < K) (running ? s_run_idx : s_fin_idx)[rank] = j;
+        }
     } else {
         for (int j = tid; j < n_keep; j += BS_THREADS) {
             const float v = s_rs[j];
