@@ -194,3 +194,79 @@ def test_random_beam_searches_against_the_oracle(block):
             # the heuristic flag only depends on placeholder slots when the best running beam is one
             decided = ref.running_beam_scores[:, 0] > LIVE
             assert torch.equal(st.unsat.cpu().bool()[decided], ref.unsat[:, 0][decided]), tag
+
+
+@pytest.mark.parametrize("block", range(3))
+def test_random_reward_rows_against_the_text_oracle(block):
+    """Rule / prefix / NDCG rewards on random code rows: lengths 0..5 on either side, hints, group sizes
+    1..20 with a trailing incomplete group, both prefix normalisations, code rows and token rows (ids
+    without a code in between) -- against the restatement of the reference's text functions."""
+    from oracle.scoring import ref_ndcg_reward, ref_prefix_reward, ref_rule_reward
+
+    from genrec_amd.rewards.ranking_reward import SidRewardScorer, score_code_rows
+
+    dev = _dev()
+    rng = np.random.default_rng(300 + block)
+    letters = "abcde"
+    for _ in range(12):
+        K = int(rng.integers(1, 21))
+        R = int(rng.integers(1, 6)) * K + (int(rng.integers(0, K)) if rng.random() < 0.4 else 0)
+        cb = int(rng.integers(2, 5))  # small codebook: plenty of exact and partial matches
+        gts = [rng.integers(0, cb, size=int(rng.integers(0, 6))).tolist() for _ in range(R)]
+        preds, hints = [], []
+        for r in range(R):
+            kind = rng.random()
+            if kind < 0.35:
+                full = list(gts[r])
+            elif kind < 0.7:
+                full = list(gts[r][: int(rng.integers(0, len(gts[r]) + 1))]) + rng.integers(0, cb, size=int(rng.integers(0, 3))).tolist()
+            else:
+                full = rng.integers(0, cb, size=int(rng.integers(0, 6))).tolist()
+            cut = int(rng.integers(0, len(full) + 1)) if rng.random() < 0.5 else 0
+            hints.append(full[:cut])
+            preds.append(full[cut:])
+
+        def text(codes, start=0):
+            return "".join(f"<{letters[(start + i) % 5]}_{c}>" for i, c in enumerate(codes))
+
+        completions = [text(p, len(h)) for p, h in zip(preds, hints)]
+        hint_texts = [text(h) for h in hints]
+        gt_texts = [text(g) for g in gts]
+        normalize = bool(rng.integers(0, 2))
+        want_rule = ref_rule_reward(completions, gt_texts, hint_texts)
+        want_prefix = ref_prefix_reward(completions, gt_texts, hint_texts, normalize=normalize)
+        want_ndcg = ref_ndcg_reward(completions, gt_texts, K, hint_texts)
+
+        # (a) int32 code rows with lengths
+        width = max(1, max(len(h) + len(p) for h, p in zip(hints, preds)), max(len(g) for g in gts))
+        pc, pl = np.zeros((R, width), np.int32), np.zeros(R, np.int32)
+        gc, gl = np.zeros((R, width), np.int32), np.zeros(R, np.int32)
+        for r in range(R):
+            full = hints[r] + preds[r]
+            pc[r, : len(full)], pl[r] = full, len(full)
+            gc[r, : len(gts[r])], gl[r] = gts[r], len(gts[r])
+        got = score_code_rows(torch.from_numpy(pc).to(dev), torch.from_numpy(pl).to(dev), torch.from_numpy(gc).to(dev),
+                              torch.from_numpy(gl).to(dev), K, normalize)
+        n_full = (R // K) * K
+        assert got["rule"].cpu().tolist() == want_rule
+        assert np.allclose(got["prefix"].cpu().numpy(), np.asarray(want_prefix, dtype=np.float32), rtol=0, atol=1e-7)
+        assert np.allclose(got["ndcg"].cpu().numpy()[:n_full], np.asarray(want_ndcg, dtype=np.float32), rtol=0, atol=1e-7)
+
+        # (b) int64 token rows through a code table; ids >= 100 carry no code (padding, EOS) and are skipped
+        table = np.full(200, -1, np.int32)
+        table[:cb] = np.arange(cb)
+        tw = width + 3
+
+        def token_rows(rows):
+            out = np.full((R, tw), 150, np.int64)
+            for r, codes in enumerate(rows):
+                slots = np.sort(rng.choice(tw, size=len(codes), replace=False))
+                out[r, slots] = codes
+            return torch.from_numpy(out).to(dev)
+
+        scorer = SidRewardScorer(table, K, dev, prefix_normalize=normalize)
+        hint_rows = token_rows(hints) if any(hints) else None
+        got_t = scorer(token_rows(preds), token_rows(gts), hint_rows)
+        assert got_t["rule"].cpu().tolist() == want_rule
+        assert np.allclose(got_t["prefix"].cpu().numpy(), np.asarray(want_prefix, dtype=np.float32), rtol=0, atol=1e-7)
+        assert np.allclose(got_t["ndcg"].cpu().numpy()[:n_full], np.asarray(want_ndcg, dtype=np.float32), rtol=0, atol=1e-7)
