@@ -353,6 +353,9 @@ def main() -> None:
         from genrec_amd.advantage import gather_rows
 
         gather_rows(torch.zeros((args.batch * args.beams, 2), dtype=torch.float32, device=device))
+    # one untimed rollout (every kernel launched once, every buffer allocated) whatever --warmup says
+    for _ in range(wl["levels"] + 1):
+        roll.step()
     for _ in range(args.warmup):
         roll.step()
     roll.depth = wl["levels"]  # the timed region starts with a fresh generation
