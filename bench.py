@@ -363,8 +363,10 @@ def main() -> None:
         from genrec_amd.advantage import gather_rows
 
         gather_rows(torch.zeros((args.batch * args.beams, 2), dtype=torch.float32, device=device))
-    # one untimed rollout (every kernel launched once, every buffer allocated) whatever --warmup says
-    for _ in range(wl["levels"] + 1):
+    # Untimed set-up, whatever --warmup says: one whole rollout and its scoring (every kernel launched
+    # once, every buffer allocated), plus as many steps as it takes for the warm-up to end on a rollout
+    # boundary -- the timed region then starts with a fresh generation without cutting one short.
+    for _ in range(wl["levels"] + 1 + (-(args.warmup + 1)) % wl["levels"]):
         roll.step()
     for _ in range(args.warmup):
         roll.step()
