@@ -386,11 +386,15 @@ __global__ __launch_bounds__(MLS_THREADS) void masked_lsm_kernel(MlsArgs a) {
         }
     }
     // Elements not covered by 16-byte vectors (all of them when !VEC); the last part of a split row.
-    if ((!SPLIT || part == a.S - 1) && !(VEC && a.skip_stream)) {
+    // Rows that are not streamed (skip_stream) are only visited here for the -inf fill of an
+    // element-wise dense output.
+    if ((!SPLIT || part == a.S - 1) && !(a.skip_stream && (VEC || OUT == OUT_COMPACT))) {
         const float ninf_f = -INFINITY;
         for (int e = (VEC ? nvec * EPV : 0) + tid; e < a.V; e += MLS_THREADS) {
-            float f[1] = {E::to_float(row[e])};
-            if (!a.skip_stream) accumulate<1>(acc, f);
+            if (!a.skip_stream) {
+                float f[1] = {E::to_float(row[e])};
+                accumulate<1>(acc, f);
+            }
             if (VEC) continue;  // pre-filled
             if (OUT == OUT_FULL_F32) {
                 reinterpret_cast<float*>(a.out)[(int64_t)r * a.out_stride + e] = ninf_f;
@@ -401,9 +405,12 @@ __global__ __launch_bounds__(MLS_THREADS) void masked_lsm_kernel(MlsArgs a) {
     }
 
     if (OUT != OUT_COMPACT && !VEC) {
-        // The -inf fill of every thread must have reached memory before any
-        // thread overwrites an allowed position.
+        // The -inf fill of every thread must have reached memory before any thread -- of
+        // any wave -- overwrites an allowed position: each thread waits for its own stores,
+        // then the workgroup meets.  (The barrier inside block_combine cannot stand in for
+        // this one: rows that are not streamed never get there.)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
     }
     typedef typename std::conditional<OUT == OUT_FULL_F32, float, T>::type OT;
     MSTAMP(3);

@@ -731,3 +731,60 @@ def test_rows_that_are_already_normalised_need_not_be_streamed(case):
     proc.check_errors()
     with pytest.raises(ValueError, match="assume_normalized"):
         _make(case, fn, meta, assume_normalized=True, repetition_penalty=1.1)
+
+
+@pytest.mark.parametrize("V", [1001, 1023, 4099])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+def test_normalised_rows_on_the_element_wise_dense_path(V, dtype):
+    """``assume_normalized=True`` where rows or output are not 16-byte aligned: the kernel fills the
+    dense row with -inf itself, nothing is streamed, and the fill of every wave must be ordered
+    before any wave scatters an allowed value (the allowed ids sit in the last columns, which are
+    filled last).  Finite set == oracle on the same input; finite entries == the input bit for bit;
+    through ``__call__`` and through ``call_into`` with a padded output view."""
+    from oracle.processors import DictTrie, RefConstrainedLogitsProcessor
+
+    from genrec_amd.logit_processor import ConstrainedLogitsProcessor
+    from genrec_amd.trie import FlatTrie, create_prefix_allowed_tokens_fn
+
+    data, meta, _, _ = _small_setup()
+    dev = _dev()
+    seqs = data["trie_sequences"].tolist()
+    fn = create_prefix_allowed_tokens_fn(FlatTrie(seqs), meta["prefix"])
+    o_trie = DictTrie(seqs)
+    K = meta["K"]
+    ids = torch.from_numpy(data["count_rl.ids.1"]).repeat(32, 1)  # many workgroups in flight at once
+    R = ids.shape[0]
+    torch.manual_seed(V + 7)
+    raw = torch.randn(R, V) * 5
+    logp = torch.log_softmax(raw, dim=-1).to(dtype)
+    ref = RefConstrainedLogitsProcessor(o_trie.get, K, 3, meta["prefix"], meta["eos"])
+    ref.count = 1
+    want = ref(ids, logp.float())  # the reference normalises once more: a near-identity
+    fin_w = torch.isfinite(want)
+    tol = FP32_TOL if dtype == torch.float32 else 0.07  # 16-bit rows are not normalised to fp32 accuracy
+    proc = ConstrainedLogitsProcessor(fn, K, 3, meta["prefix"], meta["eos"], assume_normalized=True)
+    ids_d, logp_d = ids.to(dev), logp.to(dev)
+    for rep in range(3):
+        proc.count = 1
+        got = proc(ids_d, logp_d)
+        assert got.dtype == dtype
+        for pad in (5, 3):
+            backing = torch.full((R, V + pad), 7.0, dtype=dtype, device=dev)
+            proc.count = 1
+            into = proc.call_into(ids_d, logp_d, backing[:, :V])
+            assert into.data_ptr() == backing.data_ptr()
+            assert bool((backing[:, V:] == 7.0).all()), "padding columns must stay untouched"
+            assert torch.equal(into, got)
+        g = got.cpu()
+        assert torch.equal(torch.isfinite(g), fin_w), "allowed-token sets differ"
+        assert bool((g[~fin_w] == -float("inf")).all())
+        assert torch.equal(g[fin_w], logp[fin_w])  # passed through untouched
+        assert float((g.float()[fin_w] - want[fin_w]).abs().max()) <= tol
+    if dtype != torch.float32:
+        out32 = torch.empty((R, V), dtype=torch.float32, device=dev)
+        proc.count = 1
+        proc.call_into(ids_d, logp_d, out32)
+        o = out32.cpu()
+        assert torch.equal(torch.isfinite(o), fin_w)
+        assert torch.equal(o[fin_w], logp.float()[fin_w])
+    proc.check_errors()
