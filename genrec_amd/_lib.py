@@ -37,6 +37,8 @@ EXPORTED_SYMBOLS = (
     "grx_constrained_logsoftmax",
     "grx_constrained_candidates",
     "grx_candidate_stride",
+    "grx_noalloc_max_rows",
+    "grx_constrained_candidates_noalloc",
     "grx_timing_enable",
     "grx_timing_read",
     "grx_read_probe",
@@ -195,6 +197,12 @@ def _declare(lib: C.CDLL) -> None:
     lib.grx_constrained_candidates.restype = C.c_int
     lib.grx_constrained_candidates.argtypes = [
         vp, vp, C.POINTER(GrxRows), C.POINTER(GrxConstraint), vp, i64, i32, vp, C.c_size_t, vp,
+    ]
+    lib.grx_noalloc_max_rows.restype = i32
+    lib.grx_noalloc_max_rows.argtypes = []
+    lib.grx_constrained_candidates_noalloc.restype = C.c_int
+    lib.grx_constrained_candidates_noalloc.argtypes = [
+        vp, vp, C.POINTER(GrxRows), C.POINTER(GrxConstraint), vp, i64, i32, vp,
     ]
     lib.grx_candidate_stride.restype = i64
     lib.grx_candidate_stride.argtypes = [i32]

@@ -9,6 +9,7 @@
 #include <math.h>
 #include <string.h>
 
+#include <mutex>
 #include <type_traits>
 
 #include "common.h"
@@ -874,10 +875,9 @@ extern "C" int64_t grx_candidate_stride(int32_t cmax) {
     return (((int64_t)cmax + 1 + 15) / 16) * 16;
 }
 
-extern "C" int grx_constrained_candidates(const grx_trie* trie, grx_state* state, const grx_rows* rows,
-                                          const grx_constraint* con, grx_cand* cand, int64_t cand_stride,
-                                          int32_t cmax, void* workspace, size_t workspace_bytes, void* stream) {
-    const char* who = "grx_constrained_candidates";
+static int candidates_call(const char* who, const grx_trie* trie, grx_state* state, const grx_rows* rows,
+                           const grx_constraint* con, grx_cand* cand, int64_t cand_stride, int32_t cmax,
+                           void* workspace, size_t workspace_bytes, void* stream) {
     GRX_REQUIRE(rows != nullptr, GRX_E_INVALID, "%s: null rows", who);
     GRX_REQUIRE(cmax >= 1, GRX_E_INVALID, "%s: cmax must be >= 1", who);
     GRX_REQUIRE(cand_stride >= grx_candidate_stride(cmax) && cand_stride % 16 == 0, GRX_E_INVALID,
@@ -891,4 +891,69 @@ extern "C" int grx_constrained_candidates(const grx_trie* trie, grx_state* state
     a.cmax = cmax;
     return run_step(who, trie, state, rows, con, a, OUT_COMPACT, true, workspace, workspace_bytes,
                     (hipStream_t)stream);
+}
+
+extern "C" int grx_constrained_candidates(const grx_trie* trie, grx_state* state, const grx_rows* rows,
+                                          const grx_constraint* con, grx_cand* cand, int64_t cand_stride,
+                                          int32_t cmax, void* workspace, size_t workspace_bytes, void* stream) {
+    return candidates_call("grx_constrained_candidates", trie, state, rows, con, cand, cand_stride, cmax, workspace,
+                           workspace_bytes, stream);
+}
+
+// ---- the entry point that allocates nothing -------------------------------------
+// grx_constrained_candidates with the workspace (arrival counters and partial sums of split rows,
+// fixed-hint row plans) taken from a device array that is part of the library image, for callers
+// that cannot allocate.  Each GPU holds its own copy of the array at its own address; that address
+// is looked up once per device and is what every kernel and memset below receives -- in host code
+// the array's name is only a handle for the lookup, never a pointer to pass on.
+#define GRX_NOALLOC_SCRATCH_BYTES (GRX_WS_PLAN_OFFSET + (size_t)GRX_NOALLOC_MAX_ROWS * sizeof(grx_row_plan))
+#define GRX_NOALLOC_MAX_DEVICES 64
+static __device__ __align__(256) unsigned char scratch[GRX_NOALLOC_SCRATCH_BYTES];
+static void* g_scratch_ptr[GRX_NOALLOC_MAX_DEVICES];  // device address of `scratch` on each GPU, once looked up
+static std::mutex g_scratch_mutex;
+
+static int scratch_on_current_device(const char* who, void** out) {
+    int dev = -1;
+    GRX_CHECK_HIP(hipGetDevice(&dev));
+    GRX_REQUIRE(dev >= 0 && dev < GRX_NOALLOC_MAX_DEVICES, GRX_E_UNSUPPORTED, "%s: device index %d not supported", who,
+                dev);
+    std::lock_guard<std::mutex> guard(g_scratch_mutex);
+    if (g_scratch_ptr[dev] == nullptr) {
+        void* p = nullptr;
+        GRX_CHECK_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        GRX_REQUIRE(p != nullptr && ((uintptr_t)p & 15u) == 0, GRX_E_HIP, "%s: no device address for the scratch array",
+                    who);
+        g_scratch_ptr[dev] = p;
+    }
+    *out = g_scratch_ptr[dev];
+    return GRX_OK;
+}
+
+extern "C" int32_t grx_noalloc_max_rows(void) { return GRX_NOALLOC_MAX_ROWS; }
+
+extern "C" int grx_constrained_candidates_noalloc(const grx_trie* trie, grx_state* state, const grx_rows* rows,
+                                                  const grx_constraint* con, grx_cand* cand, int64_t cand_stride,
+                                                  int32_t cmax, void* stream) {
+    const char* who = "grx_constrained_candidates_noalloc";
+    GRX_REQUIRE(rows != nullptr && trie != nullptr, GRX_E_INVALID, "%s: null trie/rows", who);
+    GRX_REQUIRE(rows->R <= GRX_NOALLOC_MAX_ROWS, GRX_E_UNSUPPORTED,
+                "%s: %d rows, the built-in scratch holds at most %d (use grx_constrained_candidates with a workspace)",
+                who, rows->R, GRX_NOALLOC_MAX_ROWS);
+    GRX_REQUIRE(rows->planned == 0, GRX_E_UNSUPPORTED,
+                "%s: rows planned ahead live in the planner's workspace; pass planned = 0", who);
+    int dev = -1;
+    GRX_CHECK_HIP(hipGetDevice(&dev));
+    GRX_REQUIRE(dev == trie->device, GRX_E_INVALID, "%s: the trie lives on device %d, current device is %d", who,
+                trie->device, dev);
+    void* ws = nullptr;
+    int rc = scratch_on_current_device(who, &ws);
+    if (rc != GRX_OK) return rc;
+    // The array keeps what the last call left in it.  Row plans are rewritten by every call that
+    // reads them; the arrival counters of split rows must start at zero, and although every
+    // completed call hands them back zeroed, a call that was abandoned half way (device reset of
+    // the stream, a capture that was dropped) would not have -- so they are cleared whenever they
+    // are about to be used.
+    if (rows->R > 0 && rows->R <= GRX_SPLIT_MAX_ROWS)
+        GRX_CHECK_HIP(hipMemsetAsync(ws, 0, GRX_SPLIT_COUNT_BYTES, (hipStream_t)stream));
+    return candidates_call(who, trie, state, rows, con, cand, cand_stride, cmax, ws, GRX_NOALLOC_SCRATCH_BYTES, stream);
 }

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define GRX_ABI_VERSION 5
+#define GRX_ABI_VERSION 6
 
 #if defined(GRX_BUILDING)
 #define GRX_API __attribute__((visibility("default")))
@@ -201,6 +201,26 @@ GRX_API int64_t grx_candidate_stride(int32_t cmax);
 GRX_API int grx_constrained_candidates(const grx_trie* trie, grx_state* state, const grx_rows* rows,
                                        const grx_constraint* con, grx_cand* cand, int64_t cand_stride, int32_t cmax,
                                        void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * grx_constrained_candidates for callers that cannot allocate device memory (no
+ * counterpart in the reference): code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc.  Same inputs, outputs and results, but no
+ * workspace argument: the scratch the kernels need (arrival counters and partial
+ * sums of split rows, fixed-hint row plans) is a device array inside the library
+ * image, GRX_NOALLOC_MAX_ROWS rows large (about 1 MB, held by every GPU the library
+ * runs on until the process ends).  The call makes no hipMalloc / hipFree and calls
+ * no allocating routine; the first call on a device looks the array's address up.
+ * More than GRX_NOALLOC_MAX_ROWS rows are refused with GRX_E_UNSUPPORTED, and so is
+ * grx_rows.planned = 1 (plans made ahead live in the planner's workspace).  All
+ * calls on one GPU share the array: calls that overlap on one GPU (two streams, two
+ * threads) race -- serialise them.  The trie must live on the current device.
+ */
+#define GRX_NOALLOC_MAX_ROWS 65536
+GRX_API int32_t grx_noalloc_max_rows(void);
+GRX_API int grx_constrained_candidates_noalloc(const grx_trie* trie, grx_state* state, const grx_rows* rows,
+                                               const grx_constraint* con, grx_cand* cand, int64_t cand_stride,
+                                               int32_t cmax, void* stream);
 
 /*
  * Kernel timing for benchmarks (no counterpart in the reference).  While

@@ -54,7 +54,8 @@ def test_plain_c_client_decodes_one_step_on_the_gpu(tmp_path):
     """Trie upload, count-based compact candidates and a beam step driven from C; the client checks
     the results against its own float64 log-softmax."""
     exe = PREBUILT
-    if not os.path.exists(exe):  # normally built beforehand by __graft_entry__.build()
+    newest_input = max(os.path.getmtime(p) for p in (SRC, os.path.join(ROOT, "include", "genrec_hip.h")))
+    if not os.path.exists(exe) or os.path.getmtime(exe) < newest_input:  # normally built by __graft_entry__.build()
         exe = str(tmp_path / "abi_client")
         _compile(exe)
     run = subprocess.run([exe, "gpu"], capture_output=True, text=True, timeout=120)
