@@ -39,6 +39,9 @@ EXPORTED_SYMBOLS = (
     "grx_candidate_stride",
     "grx_noalloc_max_rows",
     "grx_constrained_candidates_noalloc",
+    "grx_chunk_parts",
+    "grx_constrained_partial",
+    "grx_constrained_finish",
     "grx_timing_enable",
     "grx_timing_read",
     "grx_read_probe",
@@ -78,6 +81,17 @@ class GrxConstraint(C.Structure):
         ("penalty_skip", C.c_int32),
         ("assume_normalized", C.c_int32),
         ("reserved", C.c_int32),
+    ]
+
+
+class GrxChunk(C.Structure):
+    _fields_ = [
+        ("v_begin", C.c_int32),
+        ("v_total", C.c_int32),
+        ("slot", C.c_int32),
+        ("n_slots", C.c_int32),
+        ("parts", C.c_int32),
+        ("first", C.c_int32),
     ]
 
 
@@ -204,6 +218,14 @@ def _declare(lib: C.CDLL) -> None:
     lib.grx_constrained_candidates_noalloc.argtypes = [
         vp, vp, C.POINTER(GrxRows), C.POINTER(GrxConstraint), vp, i64, i32, vp,
     ]
+    lib.grx_chunk_parts.restype = i32
+    lib.grx_chunk_parts.argtypes = [i32, i32, i32]
+    lib.grx_constrained_partial.restype = C.c_int
+    lib.grx_constrained_partial.argtypes = [
+        vp, vp, C.POINTER(GrxRows), C.POINTER(GrxConstraint), C.POINTER(GrxChunk), vp, vp, i64, i32, vp, C.c_size_t, vp,
+    ]
+    lib.grx_constrained_finish.restype = C.c_int
+    lib.grx_constrained_finish.argtypes = [i32, i32, vp, vp, i64, i32, vp, C.c_size_t, vp]
     lib.grx_candidate_stride.restype = i64
     lib.grx_candidate_stride.argtypes = [i32]
     lib.grx_timing_enable.restype = C.c_int

@@ -63,6 +63,10 @@ struct grx_trie {
     int32_t chain_n;
     int32_t chain_tok[GRX_CHAIN_MAX];
     int32_t chain_node;
+    // Host copy of the distinct edge tokens, ascending: lets a call over a slice of the vocabulary
+    // know whether any allowed token can lie inside it.
+    int32_t* tok_sorted;
+    int32_t n_tok_sorted;
 };
 
 // Device words behind grx_state.  The counter and the "a row ended in

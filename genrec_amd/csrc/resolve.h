@@ -22,8 +22,9 @@ int grx_plan_ctx_for_next_call(const char* who, const grx_plan_request* req, int
 int grx_launch_plan_kernel(const PlanCtx& ctx, const int64_t* ids, int64_t ids_stride, int R, int T,
                            grx_row_plan* plan, hipStream_t stream);
 
+// `vocab`: width of the whole vocabulary when `rows` is a slice of it, -1 when rows->V is that width.
 int grx_check_step_args(const char* who, const grx_trie* trie, const grx_state* state, const grx_rows* rows,
-                        const grx_constraint* con, const void* workspace, size_t workspace_bytes);
+                        const grx_constraint* con, const void* workspace, size_t workspace_bytes, int32_t vocab = -1);
 
 // Split rows.  With few rows, one workgroup per row leaves most of the chip idle,
 // so a row is streamed by S workgroups (S a power of two, R * S <= GRX_SPLIT_MAX_PARTS).

@@ -1,8 +1,10 @@
 // Trie upload, device-resident processor state, and the preparation of a
 // processor call (integer work, one pass over the token rows).
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "common.h"
@@ -70,6 +72,19 @@ extern "C" int grx_trie_create(const int32_t* child_off, const int32_t* child_to
             table[h] = grx_edge_slot{n, child_tok[e], e + 1, 0};
         }
     }
+    {
+        std::vector<int32_t> distinct(child_tok, child_tok + n_edges);
+        std::sort(distinct.begin(), distinct.end());
+        distinct.erase(std::unique(distinct.begin(), distinct.end()), distinct.end());
+        t->n_tok_sorted = (int32_t)distinct.size();
+        t->tok_sorted = (int32_t*)malloc(sizeof(int32_t) * (distinct.size() + 1));
+        if (t->tok_sorted == nullptr) {
+            grx_set_error("grx_trie_create: out of host memory");
+            delete t;
+            return GRX_E_INVALID;
+        }
+        if (!distinct.empty()) memcpy(t->tok_sorted, distinct.data(), sizeof(int32_t) * distinct.size());
+    }
     hipError_t e = hipGetDevice(&t->device);
     if (e == hipSuccess) e = hipMalloc((void**)&t->edge_hash, sizeof(grx_edge_slot) * (size_t)slots);
     if (e == hipSuccess)
@@ -85,6 +100,7 @@ extern "C" int grx_trie_create(const int32_t* child_off, const int32_t* child_to
         if (t->child_off) (void)hipFree(t->child_off);
         if (t->child_tok) (void)hipFree(t->child_tok);
         if (t->edge_hash) (void)hipFree(t->edge_hash);
+        free(t->tok_sorted);
         delete t;
         return GRX_E_HIP;
     }
@@ -97,6 +113,7 @@ extern "C" int grx_trie_destroy(grx_trie* t) {
     (void)hipFree(t->child_off);
     (void)hipFree(t->child_tok);
     (void)hipFree(t->edge_hash);
+    free(t->tok_sorted);
     delete t;
     return GRX_OK;
 }
@@ -343,7 +360,7 @@ int grx_plan_ctx_for_next_call(const char* who, const grx_plan_request* req, int
 }
 
 int grx_check_step_args(const char* who, const grx_trie* trie, const grx_state* state, const grx_rows* rows,
-                        const grx_constraint* con, const void* workspace, size_t workspace_bytes) {
+                        const grx_constraint* con, const void* workspace, size_t workspace_bytes, int32_t vocab) {
     GRX_REQUIRE(trie && rows && con, GRX_E_INVALID, "%s: null trie/rows/constraint", who);
     GRX_REQUIRE(rows->R >= 0 && rows->T >= 0 && rows->V >= 1, GRX_E_INVALID, "%s: bad shape R=%d T=%d V=%d", who,
                 rows->R, rows->T, rows->V);
@@ -365,7 +382,8 @@ int grx_check_step_args(const char* who, const grx_trie* trie, const grx_state* 
         GRX_REQUIRE(workspace_bytes >= grx_workspace_bytes(rows->R), GRX_E_WORKSPACE,
                     "%s: workspace of %zu bytes, need %zu", who, workspace_bytes, grx_workspace_bytes(rows->R));
     }
-    GRX_REQUIRE(trie->max_token < rows->V, GRX_E_INVALID,
-                "%s: the trie holds token id %d but rows have only V=%d columns", who, trie->max_token, rows->V);
+    const int32_t width = vocab >= 0 ? vocab : rows->V;  // rows may be a slice of the vocabulary
+    GRX_REQUIRE(trie->max_token < width, GRX_E_INVALID,
+                "%s: the trie holds token id %d but rows have only V=%d columns", who, trie->max_token, width);
     return GRX_OK;
 }

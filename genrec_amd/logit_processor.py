@@ -91,6 +91,99 @@ class Candidates:
         return out
 
 
+class ChunkedStep:
+    """One processor call over column slices of the logits (``grx_constrained_partial`` per slice,
+    ``grx_constrained_finish`` at the end).  Built by ``processor.chunked_step``."""
+
+    def __init__(self, proc, input_ids, cand: Candidates, v_total: int, bounds, dtype, one_row_per_group: bool):
+        if proc.repetition_penalty != 1.0 or proc.assume_normalized:
+            raise _lib.GenrecHipError("the chunked step supports neither the fused repetition penalty nor "
+                                      "assume_normalized (both need whole rows)")
+        bounds = [(int(a), int(b)) for a, b in bounds]
+        covered = sorted(bounds)
+        if not covered or covered[0][0] != 0 or covered[-1][1] != int(v_total) or any(
+                covered[i][1] != covered[i + 1][0] for i in range(len(covered) - 1)) or any(a >= b for a, b in covered):
+            raise ValueError(f"column ranges {bounds} do not cover [0, {v_total}) exactly once")
+        _lib.require_cuda(input_ids, "input_ids")
+        assert input_ids.dim() == 2, "input_ids must be a 2D tensor"
+        if not one_row_per_group and input_ids.shape[0] % proc._num_beams != 0:
+            raise RuntimeError(
+                f"shape '[-1, {proc._num_beams}, {input_ids.shape[1]}]' is invalid for input of size {input_ids.numel()}")
+        if input_ids.dtype != torch.int64:
+            input_ids = input_ids.to(torch.int64)
+        if input_ids.shape[1] > 0 and input_ids.stride(1) != 1:
+            input_ids = input_ids.contiguous()
+        self.proc, self.ids, self.cand = proc, input_ids, cand
+        self.R = input_ids.shape[0]
+        assert cand.rows == self.R and cand.buf.device == input_ids.device
+        self.v_total = int(v_total)
+        self.dtype_code = _lib.torch_dtype_code(dtype)
+        self.dtype = dtype
+        lib = _lib.lib()
+        self.slots = {}
+        n = 0
+        for a, b in bounds:
+            parts = int(lib.grx_chunk_parts(self.R, b - a, self.dtype_code))
+            self.slots[a] = (b, n, parts)
+            n += parts
+        self.n_slots = n
+        self.index = proc._device_index(input_ids)
+        self.partials = proc._partials(self.index, self.R * n * 2)
+        self.fed = 0
+        with torch.cuda.device(self.index):
+            self.state = proc._state(self.index)
+            self.ws = proc._workspace(self.index, self.R)
+        self.con = proc._constraint()
+
+    def feed(self, v_begin: int, scores: torch.Tensor) -> None:
+        """``scores`` [rows, v_end - v_begin]: the logits of tokens ``v_begin .. v_end - 1``."""
+        proc = self.proc
+        v_end, slot, parts = self.slots[int(v_begin)]
+        _lib.require_cuda(scores, "scores")
+        if scores.shape != (self.R, v_end - v_begin) or scores.dtype != self.dtype or scores.device != self.ids.device:
+            raise ValueError(f"slice at {v_begin} must be [{self.R}, {v_end - v_begin}] {self.dtype} on {self.ids.device}")
+        if scores.stride(1) != 1:
+            scores = scores.contiguous()
+        rows = _lib.GrxRows()
+        rows.input_ids = self.ids.data_ptr()
+        rows.ids_stride = self.ids.stride(0) if self.R > 1 else max(self.ids.shape[1], 1)
+        rows.R, rows.T = self.R, self.ids.shape[1]
+        rows.scores = scores.data_ptr()
+        rows.scores_stride = scores.stride(0) if self.R > 1 else scores.shape[1]
+        rows.V = scores.shape[1]
+        rows.dtype = self.dtype_code
+        chunk = _lib.GrxChunk()
+        chunk.v_begin, chunk.v_total = int(v_begin), self.v_total
+        chunk.slot, chunk.n_slots, chunk.parts = slot, self.n_slots, parts
+        chunk.first = 1 if self.fed == 0 else 0
+        if chunk.first:
+            proc._take_planned(rows, self.ids)
+        with torch.cuda.device(self.index):
+            _lib.check(
+                _lib.lib().grx_constrained_partial(
+                    proc.trie.device_handle(self.ids.device), self.state.ptr, C.byref(rows), C.byref(self.con),
+                    C.byref(chunk), self.partials.data_ptr(), self.cand.buf.data_ptr(), self.cand.stride,
+                    self.cand.cmax, self.ws.data_ptr(), self.ws.numel(), _lib.current_stream_ptr(self.ids.device),
+                )
+            )
+        self.fed += 1
+        proc._active = self.index
+
+    def finish(self) -> Candidates:
+        if self.fed != len(self.slots):
+            raise RuntimeError(f"{self.fed} of {len(self.slots)} column slices were fed")
+        with torch.cuda.device(self.index):
+            _lib.check(
+                _lib.lib().grx_constrained_finish(
+                    self.R, self.n_slots, self.partials.data_ptr(), self.cand.buf.data_ptr(), self.cand.stride,
+                    self.cand.cmax, self.ws.data_ptr(), self.ws.numel(), _lib.current_stream_ptr(self.ids.device),
+                )
+            )
+        if self.proc.sync_errors:
+            self.proc.check_errors()
+        return self.cand
+
+
 class _TrieConstrainedBase(LogitsProcessor):
     """State and launch plumbing shared by the count-based and fixed-hint processors."""
 
@@ -132,6 +225,7 @@ class _TrieConstrainedBase(LogitsProcessor):
         self._trie: Optional[FlatTrie] = None
         self._states: dict[int, _DeviceState] = {}
         self._workspaces: dict[int, torch.Tensor] = {}
+        self._partial_bufs: dict[int, torch.Tensor] = {}
         self._active: Optional[int] = None  # device index of the last call
         self._call_seq = 0                  # processor calls made so far (host side)
         self._planned: Optional[tuple] = None  # rows whose plans a beam kernel has already written
@@ -165,6 +259,13 @@ class _TrieConstrainedBase(LogitsProcessor):
             ws = torch.zeros(nbytes, dtype=torch.uint8, device=torch.device("cuda", index))
             self._workspaces[key] = ws
         return ws
+
+    def _partials(self, index: int, n_floats: int) -> torch.Tensor:
+        buf = self._partial_bufs.get(index)
+        if buf is None or buf.numel() < n_floats:
+            buf = torch.empty(n_floats, dtype=torch.float32, device=torch.device("cuda", index))
+            self._partial_bufs[index] = buf
+        return buf
 
     # -- planning ahead (fused loop) -----------------------------------------------------
     def plan_request(self, device, n_rows: int):
@@ -348,6 +449,15 @@ class _TrieConstrainedBase(LogitsProcessor):
         self._active = index
         if self.sync_errors:
             self.check_errors()
+
+    def chunked_step(self, input_ids, cand: "Candidates", v_total: int, bounds, dtype,
+                     one_row_per_group: bool = False) -> "ChunkedStep":
+        """``candidates_into`` for logits that arrive as column slices of the vocabulary (the LM head
+        run slice by slice, so that the [rows, vocab] tensor never exists): returns a
+        :class:`ChunkedStep`; ``feed`` it every slice, then ``finish``.  ``bounds`` lists the
+        ``(v_begin, v_end)`` column ranges that will be fed; together they must cover
+        ``[0, v_total)`` exactly once.  Advances ``count`` exactly like one ``candidates_into``."""
+        return ChunkedStep(self, input_ids, cand, v_total, bounds, dtype, one_row_per_group)
 
     # -- errors ----------------------------------------------------------------------------
     def _read_state(self, index: int) -> tuple[int, int, int, int]:

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define GRX_ABI_VERSION 6
+#define GRX_ABI_VERSION 7
 
 #if defined(GRX_BUILDING)
 #define GRX_API __attribute__((visibility("default")))
@@ -221,6 +221,49 @@ GRX_API int32_t grx_noalloc_max_rows(void);
 GRX_API int grx_constrained_candidates_noalloc(const grx_trie* trie, grx_state* state, const grx_rows* rows,
                                                const grx_constraint* con, grx_cand* cand, int64_t cand_stride,
                                                int32_t cmax, void* stream);
+
+/*
+ * The same step over logits that arrive in column slices (no counterpart in the
+ * reference, where the model's forward pass materialises the whole [R, V] tensor
+ * before logit_processor.py:30 reads it: MIMIGenRec.py:79, evaluate.py:363-371).
+ * The caller runs the LM-head matmul over slices of the vocabulary -- sized so that a
+ * slice [R, Vc] stays in the memory-side cache -- and hands each slice to
+ * grx_constrained_partial as soon as it exists; the slice buffer can be reused for
+ * the next one, so the full logits never reach HBM.  A partial call streams its
+ * slice once, leaves per row `parts` partial (max, sum-of-exp) pairs in
+ * partials[r, slot .. slot + parts) and copies the raw logits of the row's allowed
+ * tokens inside the slice into the row's candidate entries.  grx_constrained_finish
+ * merges a row's n_slots pairs in slot order and turns the candidate row into the
+ * format grx_constrained_candidates emits (same tokens; log-probabilities equal up
+ * to fp32 summation order).
+ *
+ * rows->scores is the slice ([R, Vc], rows->V = Vc); column j is token v_begin + j.
+ * The slices of one step must cover [0, v_total) exactly once, all calls of a step
+ * share rows->input_ids, cand, partials and workspace, every slot in [0, n_slots)
+ * must be filled by exactly one (call, part), and the call with first = 1 -- it
+ * opens the processor call: `count` advances, rows are resolved, row errors are
+ * reported -- must be ordered before the others and grx_constrained_finish after
+ * all of them (one stream, or events).  partials is device fp32 [R, n_slots, 2].
+ * Not available with the fused repetition penalty or assume_normalized.
+ */
+#define GRX_MAX_PARTIAL_SLOTS 4096
+typedef struct grx_chunk {
+    int32_t v_begin; /* token id of column 0 of this slice                          */
+    int32_t v_total; /* width of the whole vocabulary                                */
+    int32_t slot;    /* first partial slot this call fills                          */
+    int32_t n_slots; /* partial slots per row                                       */
+    int32_t parts;   /* waves that share one row of the slice (>= 1; see grx_chunk_parts) */
+    int32_t first;   /* 1: this call opens the step (exactly one call per step)     */
+} grx_chunk;
+/* a good `parts` for R rows of Vc columns: 1 when the rows alone fill the GPU */
+GRX_API int32_t grx_chunk_parts(int32_t R, int32_t Vc, int32_t dtype);
+GRX_API int grx_constrained_partial(const grx_trie* trie, grx_state* state, const grx_rows* rows,
+                                    const grx_constraint* con, const grx_chunk* chunk, float* partials,
+                                    grx_cand* cand, int64_t cand_stride, int32_t cmax, void* workspace,
+                                    size_t workspace_bytes, void* stream);
+GRX_API int grx_constrained_finish(int32_t R, int32_t n_slots, const float* partials, grx_cand* cand,
+                                   int64_t cand_stride, int32_t cmax, const void* workspace, size_t workspace_bytes,
+                                   void* stream);
 
 /*
  * Kernel timing for benchmarks (no counterpart in the reference).  While
