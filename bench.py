@@ -29,7 +29,6 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
 
@@ -40,9 +39,8 @@ def build_workload(args, device):
 
     from genrec_amd.logit_processor import ConstrainedLogitsProcessor
     from genrec_amd.fixed_hint_logit_processor import FixedHintConstrainedLogitsProcessor
-    from genrec_amd.synth import ASSISTANT_PREFIX, SidTokenizer, sample_decode_rows
+    from genrec_amd.synth import ASSISTANT_PREFIX, SidTokenizer, sample_decode_rows, write_index_file
     from genrec_amd.trie import build_trie_from_index, create_prefix_allowed_tokens_fn
-    from helpers import write_index_file
 
     tmp = tempfile.mkdtemp(prefix="genrec_bench_")
     if args.trie.startswith("cb"):  # codebook sweep: synthetic 4-level index with the given codebook size

@@ -12,7 +12,8 @@ import os
 import threading
 
 LIB_NAME = "libgenrec_hip.so"
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
+# GENREC_AMD_LIB: load another build of the library (kernel tuning: variant builds timed side by side)
+LIB_PATH = os.environ.get("GENREC_AMD_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
 GRX_OK = 0
 GRX_F32, GRX_BF16, GRX_F16 = 0, 1, 2

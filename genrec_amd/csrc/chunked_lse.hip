@@ -11,6 +11,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+#ifndef CH_NT
+#define CH_NT 1           // 1: non-temporal loads for the slice (each byte is read once)
+#endif
+#define MLS_NT CH_NT
 #include "lse_math.h"
 #include "resolve.h"
 

@@ -25,6 +25,80 @@ from .beam import BeamSearchState
 from .logit_processor import Candidates
 
 
+class SlicedLMHead:
+    """The LM head run over column slices of the vocabulary, each slice handed to the processor's
+    sliced step as soon as it exists, so that the [rows, vocab] logits are never written out
+    (the reference's model forward materialises them and ``logit_processor.py:30`` reads them back:
+    MIMIGenRec.py:79, evaluate.py:363-371).
+
+    ``head`` is the model's output embedding (a plain ``torch.nn.Linear``).  ``slice_columns`` bounds
+    the slice buffer (rows x slice_columns elements, three of them with ``overlap``).  With
+    ``overlap`` the slice kernels run on a second stream beside the matmul of the next slice."""
+
+    def __init__(self, head: torch.nn.Linear, slice_columns: int, overlap: bool = False):
+        if type(head) is not torch.nn.Linear:
+            raise TypeError(f"the sliced LM head needs a plain torch.nn.Linear output embedding, got {type(head)}")
+        self.weight, self.bias = head.weight, head.bias
+        self.V = self.weight.shape[0]
+        cols = max(64, int(slice_columns))
+        self.bounds = [(a, min(a + cols, self.V)) for a in range(0, self.V, cols)]
+        self.cols = cols
+        self.overlap = bool(overlap)
+        self._bufs: list[torch.Tensor] = []
+        self._side: Optional[torch.cuda.Stream] = None
+
+    def _buffers(self, rows: int, like: torch.Tensor) -> list[torch.Tensor]:
+        n = 3 if self.overlap else 1
+        need = rows * self.cols
+        if len(self._bufs) != n or self._bufs[0].numel() < need or self._bufs[0].dtype != like.dtype:
+            self._bufs = [torch.empty(need, dtype=like.dtype, device=like.device) for _ in range(n)]
+        return self._bufs
+
+    def candidates_into(self, processor, input_ids: torch.Tensor, hidden: torch.Tensor, cand,
+                        one_row_per_group: bool = False) -> None:
+        """``processor.candidates_into(input_ids, hidden @ weight.T + bias, cand)`` without the logits."""
+        R = hidden.shape[0]
+        hidden = hidden.contiguous()
+        bufs = self._buffers(R, hidden)
+        call = processor.chunked_step(input_ids, cand, self.V, self.bounds, hidden.dtype,
+                                      one_row_per_group=one_row_per_group)
+        dev = hidden.device
+
+        def matmul(a, b, out):
+            if self.bias is None:
+                torch.matmul(hidden, self.weight[a:b].t(), out=out)
+            else:
+                torch.addmm(self.bias[a:b], hidden, self.weight[a:b].t(), out=out)
+
+        if not self.overlap:
+            for a, b in self.bounds:
+                buf = bufs[0][: R * (b - a)].view(R, b - a)
+                matmul(a, b, buf)
+                call.feed(a, buf)
+            call.finish()
+            return
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=dev)
+        main, side = torch.cuda.current_stream(dev), self._side
+        side.wait_stream(main)  # the rows, the candidate buffer and whoever planned the call come from there
+        free: list = [None] * len(bufs)  # event after which a slice buffer may be overwritten
+        for i, (a, b) in enumerate(self.bounds):
+            j = i % len(bufs)
+            buf = bufs[j][: R * (b - a)].view(R, b - a)
+            if free[j] is not None:
+                main.wait_event(free[j])
+            matmul(a, b, buf)
+            ready = torch.cuda.Event()
+            ready.record(main)
+            with torch.cuda.stream(side):
+                side.wait_event(ready)
+                call.feed(a, buf)
+                free[j] = torch.cuda.Event()
+                free[j].record(side)
+        main.wait_stream(side)
+        call.finish()
+
+
 @dataclass
 class ConstrainedBeamOutput:
     sequences: torch.Tensor         # [B * num_return_sequences, prompt_len + generated]
@@ -48,6 +122,8 @@ def constrained_generate(
     num_return_sequences: Optional[int] = None,
     max_steps: Optional[int] = None,
     share_prefill: bool = True,
+    lm_head_slice: Optional[int] = None,
+    lm_head_overlap: bool = False,
 ) -> ConstrainedBeamOutput:
     """``input_ids`` [B, T] (left-padded like the reference's batches) on the model's device.
 
@@ -55,6 +131,8 @@ def constrained_generate(
     ``generate(repetition_penalty=...)`` would do).  ``max_steps`` fixes the number of decoding
     steps (a trie of L levels always takes L + 1) and avoids the per-step host check of HF's loop
     condition.  ``share_prefill=False`` prefills all K copies like ``generate()`` does.
+    ``lm_head_slice`` (columns): run the LM head slice by slice through :class:`SlicedLMHead` instead
+    of materialising [rows, vocab] logits; not with a repetition penalty on the processor.
     """
     B, T = input_ids.shape
     K = int(num_beams)
@@ -80,34 +158,51 @@ def constrained_generate(
     import inspect
 
     last_only = {"logits_to_keep": 1} if "logits_to_keep" in inspect.signature(model.forward).parameters else {}
+    sliced = None
+    if lm_head_slice:
+        sliced = SlicedLMHead(model.get_output_embeddings(), lm_head_slice, lm_head_overlap)
+        body = model.base_model  # the transformer without the LM head
+
+        def forward(**kw):
+            out = body(**kw)
+            return out.last_hidden_state[:, -1, :], out.past_key_values
+    else:
+        def forward(**kw):
+            out = model(**kw, **({} if kw.get("past_key_values") is not None else last_only))
+            return out.logits[:, -1, :], out.past_key_values
+    vocab = model.get_output_embeddings().weight.shape[0] if sliced is not None else None
     # as prepare_inputs_for_generation builds them: running count of real tokens, 1 on padding
     position_ids = (attention_mask.long().cumsum(-1) - 1).masked_fill(attention_mask == 0, 1)
+    # `logits` is [rows, V] -- or, with a sliced LM head, the last hidden states [rows, H] it starts from
     if share_prefill:
-        out = model(input_ids=input_ids, attention_mask=attention_mask, position_ids=position_ids, use_cache=True,
-                    return_dict=True, **last_only)
-        cache = out.past_key_values
-        cache.batch_repeat_interleave(K)
-        logits = out.logits[:, -1, :]  # [B, V]: one row per group
+        logits, cache = forward(input_ids=input_ids, attention_mask=attention_mask, position_ids=position_ids,
+                                use_cache=True, return_dict=True)
+        cache.batch_repeat_interleave(K)  # `logits` stays [B, ...]: one row per group
         mask = attention_mask.repeat_interleave(K, dim=0)
     else:
         mask = attention_mask.repeat_interleave(K, dim=0)
-        out = model(input_ids=rows, attention_mask=mask, position_ids=position_ids.repeat_interleave(K, dim=0),
-                    use_cache=True, return_dict=True, **last_only)
-        cache = out.past_key_values
-        logits = out.logits[:, -1, :]
-    del out
+        logits, cache = forward(input_ids=rows, attention_mask=mask,
+                                position_ids=position_ids.repeat_interleave(K, dim=0), use_cache=True,
+                                return_dict=True)
     next_pos = mask.long().sum(dim=1, keepdim=True)  # position of the first generated token
+
+    def candidates(ids, x, buf, one_row_per_group=False):
+        if sliced is not None:
+            sliced.candidates_into(processor, ids, x, buf, one_row_per_group=one_row_per_group)
+        else:
+            processor.candidates_into(ids, x, buf, one_row_per_group=one_row_per_group)
 
     step = 0
     while True:
         logits = logits.contiguous()
+        V = vocab if vocab is not None else logits.shape[-1]
         if step == 0 and share_prefill:
             first = Candidates(B, cmax, dev)
-            processor.candidates_into(state.prompt_rows(), logits, first, one_row_per_group=True)
-            res = state.step(first, logits.shape[-1], planner=processor, shared_rows=True)
+            candidates(state.prompt_rows(), logits, first, one_row_per_group=True)
+            res = state.step(first, V, planner=processor, shared_rows=True)
         else:
-            processor.candidates_into(state.flat_running_sequences(), logits, cand)
-            res = state.step(cand, logits.shape[-1], planner=processor)
+            candidates(state.flat_running_sequences(), logits, cand)
+            res = state.step(cand, V, planner=processor)
         step += 1
         if max_steps is not None:
             if step >= max_steps:
@@ -120,19 +215,17 @@ def constrained_generate(
         cache.reorder_cache(res.next_parent.long())
         new_tokens = state.running_sequences.view(B * K, -1)[:, state.cur_len - 1 : state.cur_len]
         mask = torch.cat([mask, torch.ones((B * K, 1), dtype=mask.dtype, device=dev)], dim=1)
-        out = model(input_ids=new_tokens, attention_mask=mask, position_ids=next_pos, past_key_values=cache,
-                    use_cache=True, return_dict=True)
+        logits, cache = forward(input_ids=new_tokens, attention_mask=mask, position_ids=next_pos,
+                                past_key_values=cache, use_cache=True, return_dict=True)
         next_pos = next_pos + 1
-        logits = out.logits[:, -1, :]
-        cache = out.past_key_values
-        del out
     seqs, scores, bidx = state.finalize(num_return_sequences)
     processor.check_errors()
     return ConstrainedBeamOutput(seqs, scores, bidx, step)
 
 
 def make_fused_generate(model, processor, num_beams: int = 50, max_completion_length: int = 128,
-                        length_penalty: float = 1.0, max_steps: Optional[int] = None):
+                        length_penalty: float = 1.0, max_steps: Optional[int] = None,
+                        lm_head_slice: Optional[int] = None, lm_head_overlap: bool = False):
     """A ``generate(*args, **kwargs)`` to install on a model in place of the wrapper the reference
     builds in ``_make_mimigenrec_generate`` (MIMIGenRec.py:9-81): the trainer hands over every prompt
     ``num_beams`` times ([B * K, T] ``input_ids`` / ``attention_mask``), the wrapper keeps the first copy
@@ -154,7 +247,8 @@ def make_fused_generate(model, processor, num_beams: int = 50, max_completion_le
         mask = None if attention_mask is None else attention_mask.view(bs, K, dim)[:, 0, :]
         out = constrained_generate(model, prompts.contiguous(), processor, K, max_completion_length,
                                    attention_mask=None if mask is None else mask.contiguous(),
-                                   length_penalty=length_penalty, num_return_sequences=K, max_steps=max_steps)
+                                   length_penalty=length_penalty, num_return_sequences=K, max_steps=max_steps,
+                                   lm_head_slice=lm_head_slice, lm_head_overlap=lm_head_overlap)
         return out.sequences
 
     return generate

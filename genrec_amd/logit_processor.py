@@ -95,7 +95,8 @@ class ChunkedStep:
     """One processor call over column slices of the logits (``grx_constrained_partial`` per slice,
     ``grx_constrained_finish`` at the end).  Built by ``processor.chunked_step``."""
 
-    def __init__(self, proc, input_ids, cand: Candidates, v_total: int, bounds, dtype, one_row_per_group: bool):
+    def __init__(self, proc, input_ids, cand: Candidates, v_total: int, bounds, dtype, one_row_per_group: bool,
+                 parts: Optional[int] = None):
         if proc.repetition_penalty != 1.0 or proc.assume_normalized:
             raise _lib.GenrecHipError("the chunked step supports neither the fused repetition penalty nor "
                                       "assume_normalized (both need whole rows)")
@@ -123,9 +124,9 @@ class ChunkedStep:
         self.slots = {}
         n = 0
         for a, b in bounds:
-            parts = int(lib.grx_chunk_parts(self.R, b - a, self.dtype_code))
-            self.slots[a] = (b, n, parts)
-            n += parts
+            p = int(parts) if parts else int(lib.grx_chunk_parts(self.R, b - a, self.dtype_code))
+            self.slots[a] = (b, n, p)
+            n += p
         self.n_slots = n
         self.index = proc._device_index(input_ids)
         self.partials = proc._partials(self.index, self.R * n * 2)
@@ -451,13 +452,13 @@ class _TrieConstrainedBase(LogitsProcessor):
             self.check_errors()
 
     def chunked_step(self, input_ids, cand: "Candidates", v_total: int, bounds, dtype,
-                     one_row_per_group: bool = False) -> "ChunkedStep":
+                     one_row_per_group: bool = False, parts: Optional[int] = None) -> "ChunkedStep":
         """``candidates_into`` for logits that arrive as column slices of the vocabulary (the LM head
         run slice by slice, so that the [rows, vocab] tensor never exists): returns a
         :class:`ChunkedStep`; ``feed`` it every slice, then ``finish``.  ``bounds`` lists the
         ``(v_begin, v_end)`` column ranges that will be fed; together they must cover
         ``[0, v_total)`` exactly once.  Advances ``count`` exactly like one ``candidates_into``."""
-        return ChunkedStep(self, input_ids, cand, v_total, bounds, dtype, one_row_per_group)
+        return ChunkedStep(self, input_ids, cand, v_total, bounds, dtype, one_row_per_group, parts)
 
     # -- errors ----------------------------------------------------------------------------
     def _read_state(self, index: int) -> tuple[int, int, int, int]:

@@ -12,6 +12,7 @@ new tokens, which is what ``tokenizer.add_tokens(sorted(...))`` yields
 from __future__ import annotations
 
 import json
+import os
 import re
 from types import SimpleNamespace
 from typing import Iterable, Optional, Sequence
@@ -112,6 +113,26 @@ def write_index(path: str, index: dict) -> str:
     with open(path, "w", encoding="utf-8") as f:
         json.dump(index, f)
     return path
+
+
+# Item code tables of the reference's four index files (data/<name>/<name>.index.json and
+# data/Industrial_and_Scientific/id2sid.json), one int16 row of level codes per item: the workload
+# shapes of the benchmark and of the full-size tests.
+DATA_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
+INDEX_NAMES = ("Industrial_and_Scientific", "Instruments", "Games", "Arts")
+
+
+def index_from_codes(name: str) -> dict[str, list[str]]:
+    """The ``{item_id: ["<a_x>", ...]}`` index of one of the reference's data files, rebuilt from its
+    per-item code table (``genrec_amd/data/sids_<name>.npz``)."""
+    codes = np.load(os.path.join(DATA_DIR, f"sids_{name}.npz"))["codes"]
+    letters = "abcdefghij"
+    return {str(i): [f"<{letters[l]}_{int(c)}>" for l, c in enumerate(row)] for i, row in enumerate(codes)}
+
+
+def write_index_file(name: str, directory) -> str:
+    """Write that index as ``<directory>/<name>.index.json`` and return the path."""
+    return write_index(os.path.join(str(directory), f"{name}.index.json"), index_from_codes(name))
 
 
 def sample_decode_rows(

@@ -115,7 +115,7 @@ def golden_tries(ref, ref_root: str) -> None:
                 assert tok.startswith(f"<{letters[l]}_") and tok.endswith(">"), tok
                 codes[i, l] = int(tok[3:-1])
         assert keys == [str(i) for i in range(len(keys))]
-        save_npz(os.path.join(HERE, f"sids_{name}.npz"), codes=codes)
+        save_npz(os.path.join(HERE, "..", "..", "genrec_amd", "data", f"sids_{name}.npz"), codes=codes)
 
         tok = SidTokenizer.from_index(path)
         trie, suffix_ids, prefix_index = ref.evaluate.build_trie_from_index(path, tok, prefix=ASSISTANT_PREFIX)

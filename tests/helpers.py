@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-INDEX_NAMES = ("Industrial_and_Scientific", "Instruments", "Games", "Arts")
+from genrec_amd.synth import INDEX_NAMES  # noqa: E402
 
 
 def load_npz(name: str):
@@ -23,21 +23,7 @@ def load_json_gz(name: str):
         return json.load(f)
 
 
-def index_from_codes(name: str) -> dict:
-    """Rebuild the ``{item_id: ["<a_x>", ...]}`` index of a reference data file
-    from the committed per-item code table (tests/golden/sids_<name>.npz)."""
-    codes = np.load(os.path.join(GOLDEN, f"sids_{name}.npz"))["codes"]
-    letters = "abcdefghij"
-    return {
-        str(i): [f"<{letters[l]}_{int(c)}>" for l, c in enumerate(row)] for i, row in enumerate(codes)
-    }
-
-
-def write_index_file(name: str, directory) -> str:
-    path = os.path.join(str(directory), f"{name}.index.json")
-    with open(path, "w", encoding="utf-8") as f:
-        json.dump(index_from_codes(name), f)
-    return path
+from genrec_amd.synth import index_from_codes, write_index_file  # noqa: E402,F401  (re-exported for the tests)
 
 
 def live(scores, threshold: float = -1.0e8):

@@ -288,3 +288,51 @@ def test_sliced_first_step_on_one_row_per_group_and_plans_made_ahead():
         live = c0 > -1e8
         assert torch.equal(s0[live], s1[live]) and torch.equal(b0[live], b1[live])
         assert float((c0[live] - c1[live]).abs().max()) <= 1e-5
+
+
+@pytest.mark.parametrize("kind", ["count", "fixed"])
+def test_generation_with_a_sliced_lm_head_equals_generation_from_whole_logits(kind):
+    """constrained_generate(lm_head_slice=...) -- transformer body, LM head slice by slice into the
+    sliced step, one stream or two -- returns the beams of the same loop fed whole logits."""
+    from transformers import Qwen2Config, Qwen2ForCausalLM
+
+    from genrec_amd.fixed_hint_logit_processor import FixedHintConstrainedLogitsProcessor
+    from genrec_amd.generate import constrained_generate
+    from genrec_amd.logit_processor import ConstrainedLogitsProcessor
+    from genrec_amd.trie import FlatTrie, create_prefix_allowed_tokens_fn
+
+    dev = _dev()
+    data, meta = load_npz("beams.npz")
+    prefix, eos, pad, V = meta["prefix"], meta["eos"], meta["pad"], meta["V"]
+    seqs = data["trie_sequences"].tolist()
+    fn = create_prefix_allowed_tokens_fn(FlatTrie(seqs), prefix)
+    K = 8
+    torch.manual_seed(11)
+    cfg = Qwen2Config(vocab_size=V, hidden_size=32, intermediate_size=64, num_hidden_layers=2,
+                      num_attention_heads=2, num_key_value_heads=2, max_position_embeddings=128,
+                      eos_token_id=eos, pad_token_id=pad, bos_token_id=None, tie_word_embeddings=False)
+    model = Qwen2ForCausalLM(cfg).eval()
+    with torch.no_grad():
+        for p in model.parameters():
+            p.mul_(6.0)
+    model = model.to(dev)
+    cls = ConstrainedLogitsProcessor if kind == "count" else FixedHintConstrainedLogitsProcessor
+    g = torch.Generator().manual_seed(21)
+    rows, lens = [], [9, 6, 11, 8]
+    for n in lens:
+        body = torch.randint(20, 90, (n,), generator=g).tolist()
+        rows.append([pad] * (max(lens) - n) + body + prefix)
+    prompts = torch.tensor(rows, device=dev)
+    mask = (prompts != pad).long()
+    want = constrained_generate(model, prompts, cls(fn, K, 3, prefix, eos), K, 8, attention_mask=mask,
+                                eos_token_id=eos, pad_token_id=pad, length_penalty=0.0)
+    live = want.sequences_scores > -1e8
+    assert int(live.sum()) >= 12
+    for cols, overlap, share in ((64, False, True), (64, True, True), (100, True, False), (V, False, True)):
+        got = constrained_generate(model, prompts, cls(fn, K, 3, prefix, eos), K, 8, attention_mask=mask,
+                                   eos_token_id=eos, pad_token_id=pad, length_penalty=0.0, share_prefill=share,
+                                   lm_head_slice=cols, lm_head_overlap=overlap)
+        assert got.steps == want.steps
+        assert torch.equal(got.sequences[live], want.sequences[live]), (cols, overlap, share)
+        assert torch.equal(got.beam_indices[live], want.beam_indices[live])
+        assert float((got.sequences_scores[live] - want.sequences_scores[live]).abs().max()) <= 1e-4

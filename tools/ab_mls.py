@@ -19,7 +19,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 from genrec_amd import _lib  # noqa: E402
 from genrec_amd.synth import ASSISTANT_PREFIX, SidTokenizer, sample_decode_rows  # noqa: E402
 from genrec_amd.trie import build_trie_from_index  # noqa: E402
-from helpers import write_index_file  # noqa: E402
+from genrec_amd.synth import write_index_file  # noqa: E402
 
 
 def main():

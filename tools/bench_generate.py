@@ -19,7 +19,7 @@ from genrec_amd.generate import constrained_generate  # noqa: E402
 from genrec_amd.logit_processor import ConstrainedLogitsProcessor  # noqa: E402
 from genrec_amd.synth import ASSISTANT_PREFIX, SidTokenizer, sample_decode_rows  # noqa: E402
 from genrec_amd.trie import build_trie_from_index, create_prefix_allowed_tokens_fn  # noqa: E402
-from helpers import write_index_file  # noqa: E402
+from genrec_amd.synth import write_index_file  # noqa: E402
 
 
 def main():
@@ -53,11 +53,11 @@ def main():
                                   length_penalty=1.0, eos_token_id=tok.eos_token_id, pad_token_id=tok.pad_token_id,
                                   return_dict_in_generate=True, output_scores=True)
 
-    def fused(share):
+    def fused(share, cols=None, overlap=False):
         proc = ConstrainedLogitsProcessor(fn, K, pidx, suffix, tok.eos_token_id)
         return constrained_generate(model, prompts, proc, K, steps, attention_mask=mask, eos_token_id=tok.eos_token_id,
                                     pad_token_id=tok.pad_token_id, length_penalty=1.0, max_steps=steps,
-                                    share_prefill=share)
+                                    share_prefill=share, lm_head_slice=cols, lm_head_overlap=overlap)
 
     def timed(fn_, reps=3):
         fn_()
@@ -80,6 +80,14 @@ def main():
     print(f"constrained_generate, prefill per beam : {t_f1:8.1f} ms per batch  ({t_hf / t_f1:.2f}x)")
     print(f"constrained_generate, shared prefill   : {t_f2:8.1f} ms per batch  ({t_hf / t_f2:.2f}x)")
     print(f"live beams with identical sequences (bf16 model, near-ties may flip): {same * 100:.1f} %")
+    # LM head by column slices (the [rows, vocab] logits never written out); slice sized to ~128 MB
+    cols = max(1024, (128 << 20) // (B * K * 2) // 1024 * 1024)
+    for ov in (False, True):
+        t_s, d = timed(lambda: fused(True, cols, ov))
+        same = float((c.sequences[live] == d.sequences[live]).all(dim=1).float().mean())
+        print(f"constrained_generate, shared prefill, LM head in slices of {cols} columns"
+              f"{' on two streams' if ov else ''} : {t_s:8.1f} ms per batch  ({t_hf / t_s:.2f}x; "
+              f"{same * 100:.1f} % of live beams equal to whole-logits decoding)")
 
 
 if __name__ == "__main__":

@@ -20,7 +20,7 @@ from genrec_amd import _lib  # noqa: E402
 from genrec_amd.logit_processor import Candidates, ConstrainedLogitsProcessor  # noqa: E402
 from genrec_amd.synth import ASSISTANT_PREFIX, SidTokenizer, sample_decode_rows  # noqa: E402
 from genrec_amd.trie import build_trie_from_index, create_prefix_allowed_tokens_fn  # noqa: E402
-from helpers import write_index_file  # noqa: E402
+from genrec_amd.synth import write_index_file  # noqa: E402
 
 
 def main():

@@ -17,7 +17,7 @@ _lib.LIB_PATH = os.path.join(ROOT, "genrec_amd/variants/lib_stamp.so")
 from genrec_amd.logit_processor import Candidates, ConstrainedLogitsProcessor  # noqa: E402
 from genrec_amd.synth import ASSISTANT_PREFIX, SidTokenizer, sample_decode_rows  # noqa: E402
 from genrec_amd.trie import build_trie_from_index, create_prefix_allowed_tokens_fn  # noqa: E402
-from helpers import write_index_file  # noqa: E402
+from genrec_amd.synth import write_index_file  # noqa: E402
 
 dev = torch.device("cuda", 0)
 path = write_index_file("Instruments", tempfile.mkdtemp())
