@@ -98,6 +98,7 @@ class Rollout:
         self.rpf = torch.empty((self.R, 2), dtype=torch.float32, device=device)
         self.state = None
         self.depth = 0
+        self.exchange = None
         self.plan_ahead = not getattr(args, "no_plan_ahead", False)
         self.prompt_rows = wl["prompts"].repeat_interleave(args.beams, dim=0).contiguous()
 
@@ -135,7 +136,18 @@ class Rollout:
         st = self.state
         gen = st.sequences[:, :, st.prompt_len : st.cur_len].reshape(self.R, -1)
         self.scorer(gen, self.wl["gt"], want=("rule", "ndcg"), out=self.rpf)
-        self.adv = rollout_advantages(self.rpf, self.weights, self.args.beams, "group")[0]
+        # the advantages of the local groups are ready in stream order; the all-gather behind the logged
+        # global statistics runs beside the next generation and is collected one rollout later
+        if self.exchange is not None:
+            self.gathered = self.exchange.gathered_rewards_per_func()
+        self.exchange = rollout_advantages(self.rpf, self.weights, self.args.beams, "group")
+        self.adv = self.exchange.local_advantages
+
+    def finish(self):
+        """Collect the exchange of the last rollout (inside the timed region)."""
+        if self.exchange is not None:
+            self.gathered = self.exchange.gathered_rewards_per_func()
+            self.exchange = None
 
 
 def time_cpu_baseline(args, wl):
@@ -377,6 +389,7 @@ def main() -> None:
     t0 = time.perf_counter()
     for _ in range(args.steps):
         roll.step()
+    roll.finish()
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0

@@ -99,16 +99,96 @@ def ndcg_rank_penalties(batch_size: int, num_generations: int, device, process_i
     return w[idx]
 
 
+class RolloutAdvantages:
+    """Result of :func:`rollout_advantages`.
+
+    ``local_advantages`` ([R_local] fp32) is what the trainer's loss consumes
+    (``advantages[process_slice]``, fixed_hint_grpo_trainer.py:404-408) and is ready in stream order.
+    The statistics over the rows of ALL ranks that the reference logs (``rewards``, ``advantages``,
+    ``group_mean``, ``std``: fixed_hint_grpo_trainer.py:383-401, 410-430) are produced on demand:
+    the all-gather behind them is started when the object is built, and only ``wait_global()``
+    (or unpacking the object like the 5-tuple it used to be) waits for it.
+    """
+
+    def __init__(self, local, local_stats, pending, weights, num_generations, scale_rewards, eps):
+        self.local_advantages = local
+        self.local_rewards, self.local_group_mean, self.local_std = local_stats
+        self._pending = pending  # (work handle or None, gathered tensor, host staging or None)
+        self._args = (weights, num_generations, scale_rewards, eps)
+        self._global = None
+
+    def gathered_rewards_per_func(self) -> torch.Tensor:
+        """[R_global, n_funcs] rewards of all ranks (waits for the all-gather)."""
+        work, out, device = self._pending
+        if work is not None:
+            work.wait()
+            self._pending = (None, out, device)
+        if device is not None and out.device != device:  # gloo gathered on the host
+            out = out.to(device)
+            self._pending = (None, out, None)
+        return out
+
+    def wait_global(self):
+        """``(rewards, advantages, group_mean, std)`` over the rows of all ranks."""
+        if self._global is None:
+            w, K, scale, eps = self._args
+            self._global = group_advantages(self.gathered_rewards_per_func(), w, K, scale, eps)
+        return self._global
+
+    def __iter__(self):  # (local_advantages, all_advantages, rewards, group_mean, std)
+        rewards, adv, mean, std = self.wait_global()
+        return iter((self.local_advantages, adv, rewards, mean, std))
+
+    def __getitem__(self, i):
+        if i == 0:
+            return self.local_advantages
+        return tuple(self)[i]
+
+
+def _start_gather(t: torch.Tensor):
+    """Begin ``gather_rows(t)`` without waiting: (work, output tensor, device to move it to or None)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return None, t, None
+    t = t.contiguous()
+    shape = (dist.get_world_size() * t.shape[0],) + tuple(t.shape[1:])
+    if t.is_cuda and dist.get_backend() == "gloo":
+        out = torch.empty(shape, dtype=t.dtype)
+        return dist.all_gather_into_tensor(out, t.cpu(), async_op=True), out, t.device
+    out = torch.empty(shape, dtype=t.dtype, device=t.device)
+    return dist.all_gather_into_tensor(out, t, async_op=True), out, None
+
+
 def rollout_advantages(local_rewards_per_func: torch.Tensor, reward_weights: torch.Tensor, num_generations: int,
-                       scale_rewards: str = "group", process_index: Optional[int] = None):
-    """The whole exchange step of a rollout shard: all-gather the local
-    ``[R_local, n_funcs]`` rewards, normalise per group, return
-    ``(local_advantages, all_advantages, rewards, group_mean, std)``
-    (reference: fixed_hint_grpo_trainer.py:382-408)."""
-    gathered = gather_rows(local_rewards_per_func)
-    rewards, adv, mean, std = group_advantages(gathered, reward_weights, num_generations, scale_rewards)
-    if process_index is None:
-        process_index = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+                       scale_rewards: str = "group", process_index: Optional[int] = None, eps: float = 1e-4
+                       ) -> RolloutAdvantages:
+    """The exchange step of a rollout shard (reference: fixed_hint_grpo_trainer.py:382-408): the
+    ``[R_local, n_funcs]`` rewards of all ranks are all-gathered, rewards are weighted and summed,
+    advantages normalised per group of ``num_generations`` rows, and the local rows kept.
+
+    Whole groups live on one rank, so for ``scale_rewards`` "group" and "none" a rank's advantages
+    follow from its own rows alone: they are computed at once from the local rewards -- the same
+    values the reference slices out of the gathered result -- while the all-gather (needed for the
+    logged statistics only) runs beside them.  "batch" divides by the std over the rows of all
+    ranks, so there the gather comes first.  Returns a :class:`RolloutAdvantages`.
+    """
+    if scale_rewards not in _SCALE:
+        raise ValueError(
+            f"Invalid value for scale_rewards: {scale_rewards}. Must be one of 'batch', 'group', or 'none'."
+        )
+    pending = _start_gather(local_rewards_per_func)
     n_local = local_rewards_per_func.shape[0]
-    local = adv[process_index * n_local : (process_index + 1) * n_local]
-    return local, adv, rewards, mean, std
+    if scale_rewards == "batch" and pending[0] is not None:
+        res = RolloutAdvantages(None, (None, None, None), pending, reward_weights, num_generations, scale_rewards, eps)
+        rewards, adv, mean, std = res.wait_global()
+        if process_index is None:
+            process_index = dist.get_rank()
+        sl = slice(process_index * n_local, (process_index + 1) * n_local)
+        res.local_advantages = adv[sl]
+        res.local_rewards, res.local_group_mean, res.local_std = rewards[sl], mean[sl], std[sl]
+        return res
+    rewards, adv, mean, std = group_advantages(local_rewards_per_func, reward_weights, num_generations,
+                                               scale_rewards, eps)
+    res = RolloutAdvantages(adv, (rewards, mean, std), pending, reward_weights, num_generations, scale_rewards, eps)
+    if pending[0] is None and pending[2] is None:  # one process: the local rows are all rows
+        res._global = (rewards, adv, mean, std)
+    return res

@@ -61,6 +61,9 @@ class BeamSearchState:
         # when every beam of a group starts from the same prompt, re-ordering beams never changes
         # positions < prompt_len, so the kernel only moves the generated suffix
         self.copy_from = cur_len if shared_prompt else 0
+        # transformers' own expression (generation/utils.py:3319 of 5.15.0): `pad_token_id or eos_token_id[0]`,
+        # under which a pad token id of 0 counts as absent and finished rows trail EOS.  Kept as is: the
+        # contract is generate()'s output, and its recorded traces (pad 0, eos 2) do trail EOS.
         self.fill = (pad_token_id or eos_token_id) if eos_token_id is not None else -1
         B, K, L = self.B, self.K, self.max_length
         lg = L - cur_len

@@ -7,8 +7,9 @@ appended to the prompt, until every group has a hit or reached its depth cap.
 It works on text: hint strings, decoded completions, a regular expression per
 row.  Here the same control flow runs on device tensors: hinted prompts are
 built by indexing, rule hits come from the reward kernel, group selection is a
-masked copy, and the host only learns how many groups are left per stage (the
-reference synchronises there as well: ``accelerator.gather(flag).max().item()``,
+masked copy over the whole stage batch, and the host reads back one packed triple per stage --
+groups hit, groups selected, "some rank still has unresolved groups" -- to size the next stage
+(the reference synchronises there as well: ``accelerator.gather(flag).max().item()``,
 fixed_hint_grpo_trainer.py:511-521).
 """
 
@@ -42,6 +43,23 @@ def any_rank_unresolved(n_local_unresolved: int, device, group=None) -> bool:
     flag = torch.tensor([1 if n_local_unresolved > 0 else 0], dtype=torch.int32, device=flag_device)
     dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
     return bool(flag.item())
+
+
+def _stage_sync(counts: torch.Tensor, n_local: int, device, group=None) -> tuple[int, int, bool]:
+    """The one device-to-host read of a cascade stage: ``counts`` = [groups with a rule hit, groups
+    selected] of this rank's stage batch of ``n_local`` groups, plus the consensus whether any rank
+    still has unresolved groups (fixed_hint_grpo_trainer.py:511-521).  With RCCL the consensus is
+    reduced on the device ahead of the read, so the three numbers come back together."""
+    import torch.distributed as dist
+
+    alone = not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1
+    if not alone and counts.is_cuda and dist.get_backend(group) == "nccl":
+        flag = ((n_local - counts[1]) > 0).to(torch.int32).reshape(1)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+        hit, picked, go_on = torch.cat([counts, flag]).tolist()
+        return int(hit), int(picked), bool(go_on)
+    hit, picked = (int(v) for v in counts.tolist())
+    return hit, picked, any_rank_unresolved(n_local - picked, device, group)
 
 
 def hinted_prompts(prompt_ids: torch.Tensor, gt_ids: torch.Tensor, depths: torch.Tensor, width: int,
@@ -87,14 +105,14 @@ def run_dynamic_hint_cascade(
     cap = (torch.full((G,), int(max_hint_depth), dtype=torch.int32, device=dev) if depth_cap is None
            else depth_cap.to(device=dev, dtype=torch.int32).clamp(0, int(max_hint_depth)))
     unresolved = torch.ones(G, dtype=torch.bool, device=dev)
+    order = torch.arange(G, device=dev)  # unresolved groups first, in index order
+    n_local = G                          # how many of them: the one thing the host tracks
     res: Optional[CascadeResult] = None
     stats = []
     for depth in range(int(max_hint_depth) + 1):
-        idx = torch.nonzero(unresolved).flatten()          # host sync: the stage batch is sized from it
-        n_local = int(idx.numel())
         dummy = n_local == 0
-        if dummy:                                           # keep generating with the other ranks (594-596)
-            idx = torch.zeros(1, dtype=torch.int64, device=dev)
+        # a rank that is done keeps generating with the others on one dummy group (594-596)
+        idx = torch.zeros(1, dtype=torch.int64, device=dev) if dummy else order[:n_local]
         d = torch.minimum(torch.full_like(cap[idx], depth), cap[idx])
         stage_prompts = hinted_prompts(prompt_ids[idx], gt_ids[idx], d, width, pad_token_id)
         comp = generate_stage(stage_prompts, d, idx)
@@ -109,7 +127,7 @@ def run_dynamic_hint_cascade(
                 rule_hit_any=torch.zeros(G, dtype=torch.bool, device=dev),
                 rule_rewards=torch.zeros(G * K, dtype=torch.float32, device=dev),
             )
-        hit_groups = picked = 0
+        counts = torch.zeros(2, dtype=torch.int32, device=dev)  # groups with a rule hit, groups selected
         if not dummy:
             # hint tokens beyond each group's depth are replaced by padding, which carries no SID code
             hint = gt_ids[idx][:, : max(int(max_hint_depth), 1)]
@@ -119,22 +137,25 @@ def run_dynamic_hint_cascade(
                           want=("rule",))["rule"]
             hit_any = rule.view(-1, K).max(dim=1).values > 0
             take = hit_any | (cap[idx] == depth)
-            sel = idx[take]
-            rows = (sel[:, None] * K + torch.arange(K, device=dev)[None, :]).flatten()
-            src_rows = (torch.nonzero(take).flatten()[:, None] * K + torch.arange(K, device=dev)[None, :]).flatten()
-            res.completion_ids[rows] = comp[src_rows]
-            res.rule_rewards[rows] = rule[src_rows]
-            res.prompt_ids[sel] = stage_prompts[take]
-            res.hint_depth[sel] = depth
-            res.prompt_hint_depth[sel] = d[take]
-            res.rule_hit_any[sel] = hit_any[take]
-            unresolved[sel] = False
-            hit_groups, picked = int(hit_any.sum()), int(take.sum())
+            # masked copies over the whole stage batch: nothing here needs to know how many groups were taken
+            rows = (idx[:, None] * K + torch.arange(K, device=dev)[None, :]).flatten()
+            take_rows = take.repeat_interleave(K)
+            res.completion_ids[rows] = torch.where(take_rows[:, None], comp, res.completion_ids[rows])
+            res.rule_rewards[rows] = torch.where(take_rows, rule.to(torch.float32), res.rule_rewards[rows])
+            res.prompt_ids[idx] = torch.where(take[:, None], stage_prompts, res.prompt_ids[idx])
+            res.hint_depth[idx] = torch.where(take, torch.full_like(d, depth), res.hint_depth[idx])
+            res.prompt_hint_depth[idx] = torch.where(take, d, res.prompt_hint_depth[idx])
+            res.rule_hit_any[idx] = torch.where(take, hit_any, res.rule_hit_any[idx])
+            unresolved[idx] = ~take
+            order = torch.argsort((~unresolved).to(torch.int8), stable=True)
+            counts = torch.stack([hit_any.sum(), take.sum()]).to(torch.int32)
+        hit_groups, picked, go_on = _stage_sync(counts, n_local, dev, group)
         n_left = n_local - picked
         stats.append({"requested_hint_depth": depth, "evaluated_group_count": n_local,
                       "rule_hit_group_count": hit_groups, "selected_group_count": picked,
                       "remaining_group_count": n_left})
-        if not any_rank_unresolved(n_left, dev, group):
+        n_local = n_left
+        if not go_on:
             break
     if bool((res.hint_depth < 0).any()):
         raise RuntimeError("Dynamic hint cascade left prompt groups without a selected stage.")

@@ -160,18 +160,6 @@ extern "C" int grx_hit_ranks(const int32_t* beams, const int32_t* target, int32_
 }
 
 // ------------------------------------------------------------ advantage ---
-__device__ __forceinline__ double block_sum_f64(double v, double* s_tmp) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, GRX_WAVE);
-    const int lane = threadIdx.x & (GRX_WAVE - 1), wave = threadIdx.x / GRX_WAVE;
-    __syncthreads();  // s_tmp may still be read from a previous call
-    if (lane == 0) s_tmp[wave] = v;
-    __syncthreads();
-    double t = 0.0;
-    for (int w = 0; w < SC_THREADS / GRX_WAVE; ++w) t += s_tmp[w];
-    return t;
-}
-
 __device__ __forceinline__ float weighted_nansum(const float* __restrict__ rpf, const float* __restrict__ w, int r,
                                                  int n_funcs) {
     float acc = 0.0f;
@@ -182,29 +170,47 @@ __device__ __forceinline__ float weighted_nansum(const float* __restrict__ rpf, 
     return acc;
 }
 
-// One thread per row; a workgroup holds whole groups.  scale: 0 none, 1 group, 2 batch.
+// Unbiased std of all R weighted rewards (scale "batch"), computed ONCE by a single workgroup in two
+// passes over the L2-resident rewards (fp64 sums) and left in stats[0] for the kernel below.
+#define BS_STAT_THREADS 1024
+__global__ __launch_bounds__(BS_STAT_THREADS) void batch_std_kernel(const float* __restrict__ rpf,
+                                                                    const float* __restrict__ w, int R, int n_funcs,
+                                                                    float* __restrict__ stats) {
+    __shared__ double s_tmp[BS_STAT_THREADS / GRX_WAVE];
+    const int lane = threadIdx.x & (GRX_WAVE - 1), wave = threadIdx.x / GRX_WAVE;
+    auto block_sum = [&](double v) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, GRX_WAVE);
+        __syncthreads();
+        if (lane == 0) s_tmp[wave] = v;
+        __syncthreads();
+        double t = 0.0;
+        for (int i = 0; i < BS_STAT_THREADS / GRX_WAVE; ++i) t += s_tmp[i];
+        return t;
+    };
+    double s = 0.0;
+    for (int r = threadIdx.x; r < R; r += BS_STAT_THREADS) s += (double)weighted_nansum(rpf, w, r, n_funcs);
+    const double mean = block_sum(s) / (double)R;
+    double q = 0.0;
+    for (int r = threadIdx.x; r < R; r += BS_STAT_THREADS) {
+        const double dlt = (double)weighted_nansum(rpf, w, r, n_funcs) - mean;
+        q += dlt * dlt;
+    }
+    const double m2 = block_sum(q);
+    if (threadIdx.x == 0) stats[0] = (float)sqrt(m2 / (double)(R - 1));  // R == 1: 0 / 0 = nan, as torch.std
+}
+
+// One thread per row; a workgroup holds whole groups.  scale: 0 none, 1 group, 2 batch (std from
+// batch_stats[0]).
 __global__ __launch_bounds__(SC_THREADS) void group_advantage_kernel(const float* __restrict__ rpf,
                                                                       const float* __restrict__ w, int R, int n_funcs,
                                                                       int K, int rows_per_block, int scale, float eps,
+                                                                      const float* __restrict__ batch_stats,
                                                                       float* __restrict__ rewards,
                                                                       float* __restrict__ adv,
                                                                       float* __restrict__ gmean,
                                                                       float* __restrict__ gstd) {
-    __shared__ double s_tmp[SC_THREADS / GRX_WAVE];
     __shared__ float s_rew[SC_THREADS];
-    float batch_std = 0.0f;
-    if (scale == 2) {
-        // every workgroup recomputes the unbiased std of all R rewards (R is small)
-        double s = 0.0;
-        for (int r = threadIdx.x; r < R; r += SC_THREADS) s += (double)weighted_nansum(rpf, w, r, n_funcs);
-        const double mean = block_sum_f64(s, s_tmp) / (double)R;
-        double q = 0.0;
-        for (int r = threadIdx.x; r < R; r += SC_THREADS) {
-            const double dlt = (double)weighted_nansum(rpf, w, r, n_funcs) - mean;
-            q += dlt * dlt;
-        }
-        batch_std = (float)sqrt(block_sum_f64(q, s_tmp) / (double)(R - 1));
-    }
     const int t = threadIdx.x;
     const int r = blockIdx.x * rows_per_block + t;
     const bool active = t < rows_per_block && r < R;
@@ -223,7 +229,7 @@ __global__ __launch_bounds__(SC_THREADS) void group_advantage_kernel(const float
     }
     const float mean = (float)mean_d;
     const float gsd = (float)sqrt(q / (double)(K - 1));
-    const float sd = (scale == 2) ? batch_std : gsd;
+    const float sd = (scale == 2) ? batch_stats[0] : gsd;
     float a = rew - mean;
     if (scale != 0) a = a / (sd + eps);
     if (rewards) rewards[r] = rew;
@@ -234,19 +240,29 @@ __global__ __launch_bounds__(SC_THREADS) void group_advantage_kernel(const float
 
 extern "C" int grx_group_advantage(const float* rewards_per_func, const float* weights, int32_t R, int32_t n_funcs,
                                    int32_t K, int32_t scale, float eps, float* rewards, float* advantages,
-                                   float* group_mean, float* group_std, void* stream) {
+                                   float* group_mean, float* group_std, void* stream_) {
     const char* who = "grx_group_advantage";
+    hipStream_t stream = (hipStream_t)stream_;
     GRX_REQUIRE(R >= 0 && n_funcs >= 1 && K >= 1, GRX_E_INVALID, "%s: bad shape", who);
     GRX_REQUIRE(K <= SC_THREADS, GRX_E_UNSUPPORTED, "%s: at most %d rows per group", who, SC_THREADS);
     GRX_REQUIRE(R % K == 0, GRX_E_INVALID, "%s: %d rows do not split into groups of %d", who, R, K);
     GRX_REQUIRE(scale >= 0 && scale <= 2, GRX_E_INVALID, "%s: bad scale %d", who, scale);
     if (R == 0) return GRX_OK;
     GRX_REQUIRE(rewards_per_func && weights, GRX_E_INVALID, "%s: null input", who);
+    float* stats = nullptr;
+    if (scale == 2) {
+        // one word of stream-ordered scratch for the batch std (freed in stream order below)
+        GRX_CHECK_HIP(hipMallocAsync((void**)&stats, 16, stream));
+        hipLaunchKernelGGL(batch_std_kernel, dim3(1), dim3(BS_STAT_THREADS), 0, stream, rewards_per_func, weights, R,
+                           n_funcs, stats);
+    }
     const int rows_per_block = (SC_THREADS / K) * K;
     hipLaunchKernelGGL(group_advantage_kernel, dim3((R + rows_per_block - 1) / rows_per_block), dim3(SC_THREADS), 0,
-                       (hipStream_t)stream, rewards_per_func, weights, R, n_funcs, K, rows_per_block, scale, eps,
-                       rewards, advantages, group_mean, group_std);
-    GRX_CHECK_HIP(hipGetLastError());
+                       stream, rewards_per_func, weights, R, n_funcs, K, rows_per_block, scale, eps, stats, rewards,
+                       advantages, group_mean, group_std);
+    const hipError_t launched = hipGetLastError();
+    if (stats) (void)hipFreeAsync(stats, stream);
+    GRX_CHECK_HIP(launched);
     return GRX_OK;
 }
 

@@ -27,8 +27,12 @@ _EMPTY_MSG = "No valid tokens for prefix_ids"
 _NOMATCH_MSG = "Failed to find a valid trie prefix match inside current sequence."
 
 
-def _eager_errors_default() -> bool:
-    return os.environ.get("GENREC_AMD_EAGER_ERRORS", "0") not in ("", "0", "false", "False")
+def _eager_errors_env() -> Optional[bool]:
+    """GENREC_AMD_EAGER_ERRORS=1 / 0 forces eager / deferred error reporting everywhere; unset: the default."""
+    v = os.environ.get("GENREC_AMD_EAGER_ERRORS")
+    if v is None or v == "":
+        return None
+    return v not in ("0", "false", "False")
 
 
 class _DeviceState:
@@ -208,7 +212,15 @@ class _TrieConstrainedBase(LogitsProcessor):
         self.prefix_index = prefix_index
         self.eos_token_id = eos_token_id
         self.prefix_ids = prefix_ids
-        self.sync_errors = _eager_errors_default() if sync_errors is None else bool(sync_errors)
+        # When do the reference's exceptions (logit_processor.py:43-44, fixed_hint_logit_processor.py:37-40,
+        # 59-60) surface?  The kernels record the first failing row on the device; raising needs a read-back.
+        # Default: the processor surface (`__call__`, what generate() drives -- a loop that synchronises every
+        # step anyway) raises inside the call like the reference; the fused forms (`candidates_into`, the
+        # sliced step) defer to reset() / `count` / check_errors() so that decode steps stay asynchronous.
+        # sync_errors=True / False (or GENREC_AMD_EAGER_ERRORS=1 / 0) forces one behaviour for both.
+        forced = _eager_errors_env() if sync_errors is None else bool(sync_errors)
+        self.sync_errors = bool(forced)            # fused forms
+        self.sync_errors_dense = True if forced is None else bool(forced)
         # Extension: transformers' RepetitionPenaltyLogitsProcessor folded into the same pass.
         # generate() runs that processor on log_softmax(logits) right before this one when
         # repetition_penalty != 1 (evaluate.py:218 sets 1.1); callers of the fused loop, which
@@ -402,7 +414,7 @@ class _TrieConstrainedBase(LogitsProcessor):
                 )
             )
         self._active = index
-        if self.sync_errors:
+        if self.sync_errors_dense:
             self.check_errors()
         return out
 
@@ -477,8 +489,8 @@ class _TrieConstrainedBase(LogitsProcessor):
 
         The kernels record the first (lowest-row) failure of a call on the
         device; reading it back synchronises the stream.  Called after every
-        ``__call__`` when ``sync_errors`` is set (or ``GENREC_AMD_EAGER_ERRORS=1``),
-        otherwise from ``reset()`` and when ``count`` is read.
+        ``__call__`` (unless ``sync_errors=False`` / ``GENREC_AMD_EAGER_ERRORS=0``); the fused forms
+        leave it to ``reset()``, reading ``count``, or an explicit call.
         """
         for index in list(self._states):
             _, code, row, _ = self._read_state(index)

@@ -113,28 +113,38 @@ def compute_metrics(test_data: list, topk_list: list = None, save_path: Optional
         targets.append(code(tgt))
         width = max(width, len(preds))
     lens = [len(r) for r in rows]
-    if width == 0 or min(lens) != max(lens) or (n_beam > 0 and width != n_beam):
-        # ragged prediction lists: the reference skips a cut-off k for samples shorter than k
-        # (evaluate.py:169-170); that per-sample rule is not what the histogram encodes
-        raise ValueError("compute_metrics expects the same number of predictions for every sample")
-    if not torch.cuda.is_available():
+    if width > 0 and not torch.cuda.is_available():
         raise _lib.GenrecHipError("compute_metrics ranks on the GPU; no HIP device is visible and there is no CPU path")
-    dev = torch.device("cuda", torch.cuda.current_device())
-    beams = torch.tensor(rows, dtype=torch.int32, device=dev).view(n, width, 1)
-    tgt = torch.tensor(targets, dtype=torch.int32, device=dev).view(n, 1)
-    _, hist = hit_ranks(beams, tgt)
-    metrics = metrics_from_histogram(hist.cpu(), n, width if n_beam > 0 else 0, topk_list)
-    if n_beam == 0:
-        # evaluate.py:143 keeps every k when the first sample has no predictions; with width
-        # predictions per sample only k <= width can hit (evaluate.py:169-170)
-        metrics = {}
-        valid = list(topk_list)
-        h = [int(x) for x in hist.cpu().tolist()]
-        for k in valid:
-            hr = sum(h[:k]) if k <= width else 0
-            dcg = sum(h[r] / math.log(r + 2) for r in range(k)) if k <= width else 0.0
-            metrics[f"HR@{k}"] = hr / n
-            metrics[f"NDCG@{k}"] = dcg / n / (1.0 / math.log(2))
+    uniform = min(lens) == max(lens) and width == n_beam
+    if width == 0:
+        first = [0] * n  # no predictions anywhere: no cut-off can hit
+    else:
+        dev = torch.device("cuda", torch.cuda.current_device())
+        # shorter prediction lists are padded with a code no target has
+        padded = [r + [-1] * (width - len(r)) for r in rows]
+        beams = torch.tensor(padded, dtype=torch.int32, device=dev).view(n, width, 1)
+        tgt = torch.tensor(targets, dtype=torch.int32, device=dev).view(n, 1)
+        first_hit, hist = hit_ranks(beams, tgt)
+        if uniform:
+            metrics = metrics_from_histogram(hist.cpu(), n, n_beam, topk_list)
+            if metrics and save_path:
+                save_metrics(metrics, save_path, [k for k in topk_list if f"HR@{k}" in metrics])
+            return metrics
+        first = first_hit.cpu().tolist()
+    # Prediction lists of different lengths (or a first sample without predictions, which makes every
+    # cut-off valid): the reference takes the cut-offs from the first sample and skips, per sample, every
+    # k larger than that sample's own list (evaluate.py:137-143, 168-170).  The ranks are known; the
+    # per-sample rule is applied on the host.
+    valid = [k for k in topk_list if k <= n_beam] if n_beam > 0 else list(topk_list)
+    metrics = {}
+    for k in valid:
+        hr, dcg = 0, 0.0
+        for i in range(n):
+            if k <= lens[i] and first[i] < k:
+                hr += 1
+                dcg += 1.0 / math.log(first[i] + 2)
+        metrics[f"HR@{k}"] = hr / n
+        metrics[f"NDCG@{k}"] = dcg / n / (1.0 / math.log(2))
     if metrics and save_path:
         save_metrics(metrics, save_path, [k for k in topk_list if f"HR@{k}" in metrics])
     return metrics

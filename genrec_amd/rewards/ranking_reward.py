@@ -67,13 +67,17 @@ def ndcg_rank_weights(num_beams: int) -> list[float]:
     return [-w / total for w in raw]
 
 
-def _pack_codes(rows: Sequence[Sequence[int]]) -> tuple[np.ndarray, np.ndarray]:
+def _pack_codes(rows: Sequence[Sequence[int]], ids: dict) -> tuple[np.ndarray, np.ndarray]:
+    """int32 rows for the kernel.  The reference compares Python integers of any size
+    (``re.findall(r"_(\\d+)")`` on free text can yield more digits than int32 holds), and only
+    equality matters: every distinct value is replaced by a small id from ``ids``, which the
+    prediction and ground-truth sides share."""
     lens = np.fromiter((len(r) for r in rows), dtype=np.int32, count=len(rows))
     width = max(int(lens.max()) if len(rows) else 0, 1)
     codes = np.zeros((len(rows), width), dtype=np.int32)
     for i, r in enumerate(rows):
         if r:
-            codes[i, : len(r)] = r
+            codes[i, : len(r)] = [ids.setdefault(v, len(ids)) for v in r]
     return codes, lens
 
 
@@ -163,8 +167,9 @@ def score_token_rows(pred_tok: torch.Tensor, gt_tok: torch.Tensor, code_table: t
 def _score_texts(completions, reward_kwargs, num_beams: int, prefix_normalize: bool, want) -> dict[str, list[float]]:
     reward_model = _extract_reward_model_from_kwargs(reward_kwargs)
     texts = _full_texts(completions, reward_kwargs)
-    pred, pred_len = _pack_codes([_extract_number(t) for t in texts])
-    gt, gt_len = _pack_codes([_extract_number(reward_model[i]["ground_truth"]) for i in range(len(texts))])
+    ids: dict = {}
+    pred, pred_len = _pack_codes([_extract_number(t) for t in texts], ids)
+    gt, gt_len = _pack_codes([_extract_number(reward_model[i]["ground_truth"]) for i in range(len(texts))], ids)
     dev = _default_device()
     res = score_code_rows(
         torch.from_numpy(pred).to(dev), torch.from_numpy(pred_len).to(dev), torch.from_numpy(gt).to(dev),

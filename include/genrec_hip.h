@@ -309,6 +309,12 @@ GRX_API int grx_read_probe(const void* rows, int64_t stride_bytes, int32_t R, in
  * dropped plan recorded in the state, and so does a second plan made ahead of the
  * same call.  planned = 1 is only valid for exactly the rows that were planned,
  * with no grx_state_set_count since.
+ * One workspace per search: in the fixed-hint mode grx_beam_step derives a row's
+ * plan from the plan of its parent row, which it reads from this same `workspace`
+ * -- so the processor call that produced the candidates handed to grx_beam_step
+ * must have run on B * K rows with this workspace (or, with cand_shared, on B rows;
+ * then nothing is read back).  A workspace that did not serve that call yields
+ * plans for the wrong rows.
  */
 typedef struct grx_plan_request {
     const grx_trie* trie;
@@ -460,7 +466,9 @@ GRX_API int grx_hit_ranks(const int32_t* beams, const int32_t* target, int32_t n
  * (token_prefix_grpo_trainer.py:41-45).  rewards_per_func is device fp32
  * [R, n_funcs] (after the all-gather), weights device fp32 [n_funcs].
  * Outputs (device fp32 [R], any may be NULL): rewards, advantages,
- * group_mean, group_std.
+ * group_mean, group_std.  Scale 2 first reduces all R rows once (one extra
+ * single-workgroup kernel) into a word of stream-ordered scratch
+ * (hipMallocAsync / hipFreeAsync on `stream`); scales 0 and 1 allocate nothing.
  */
 GRX_API int grx_group_advantage(const float* rewards_per_func, const float* weights, int32_t R, int32_t n_funcs,
                         int32_t K, int32_t scale, float eps, float* rewards, float* advantages,

@@ -41,6 +41,25 @@ def _worker(rank: int, world: int, port: int, out_dir: str):
         _, adv_b, _, std_b = ref_group_advantage(gathered, w, K, "batch")
         _, _, _, std_b_local = ref_group_advantage(local, w, K, "batch")
         assert not torch.equal(std_b[:1], std_b_local[:1])
+        # the product's exchange step (async gather, local-first advantages, slice of the global result in
+        # "batch" mode) with the kernel swapped for the oracle, which runs on CPU tensors
+        import genrec_amd.advantage as adv_mod
+
+        def cpu_group_advantages(rpf, weights, K_, scale, eps=1e-4):
+            r, a, m, s_ = ref_group_advantage(rpf, weights, K_, scale)
+            return r, a, m, s_.expand_as(r) if s_.dim() == 0 else s_
+
+        adv_mod.group_advantages = cpu_group_advantages
+        for scale in ("group", "batch", "none"):
+            want = cpu_group_advantages(full, w, K, scale)
+            res = adv_mod.rollout_advantages(local, w, K, scale)
+            sl = slice(rank * n_local, (rank + 1) * n_local)
+            assert torch.equal(res.local_advantages, want[1][sl]), scale
+            assert torch.equal(res.local_rewards, want[0][sl]) and torch.equal(res.local_std, want[3][sl])
+            assert torch.equal(res.gathered_rewards_per_func(), full)
+            for got_t, want_t in zip(res.wait_global(), want):
+                assert torch.equal(got_t, want_t), scale
+            assert torch.equal(res[0], want[1][sl]) and torch.equal(tuple(res)[1], want[1])
         one = gather_rows(torch.tensor([float(rank)]))
         assert one.tolist() == [float(r) for r in range(world)]
         torch.save(mine, os.path.join(out_dir, f"adv{rank}.pt"))

@@ -215,6 +215,12 @@ def test_fused_loop_on_a_ragged_trie_in_every_stopping_mode():
         assert torch.equal(got_seqs[:, :w][live], want_seqs[:, :w][live]), name
         assert torch.equal(got_bidx[:, :bw].long()[live], want_bidx[:, :bw].long()[live]), name
         assert float((got_scores[live] - want_scores[live]).abs().max()) <= SCORE_TOL, name
+        # generate() fills finished rows with `pad_token_id or eos_token_id` (utils.py:3319): with the
+        # recorded pad id 0 the rows trail EOS, not 0 -- and so must ours
+        assert pad == 0 and eos != 0
+        short = live & (want_seqs[:, w - 1] == eos) & (want_seqs[:, w - 2] == eos)
+        assert bool(short.any()) and not bool((want_seqs[live][:, prompts.shape[1]:] == pad).any()), name
+        assert not bool((got_seqs[:, :w][live][:, prompts.shape[1]:] == pad).any()), name
 
 
 @pytest.mark.parametrize("vouched", [False, True])

@@ -1,0 +1,23 @@
+"""The rollout's exchange step with world_size 2 on the GPU: every rank's advantages, the gathered
+rewards and the global statistics equal a single-process run over the concatenated rows, for
+scale_rewards "group", "batch" and "none" (reference: fixed_hint_grpo_trainer.py:382-408).  Two ranks
+share the one GPU of the test box, so the process group is gloo; the kernels and the slicing logic are
+the ones an RCCL job runs."""
+
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_two_ranks_get_the_single_process_values():
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29617", os.path.join(ROOT, "tests", "workers", "exchange_ranks.py")]
+    run = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=200)
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-4000:]
+    assert "exchange rank 0 ok" in run.stdout and "exchange rank 1 ok" in run.stdout

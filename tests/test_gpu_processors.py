@@ -116,6 +116,18 @@ def test_reference_error_conventions():
     with pytest.raises(ValueError, match="Failed to find a valid trie prefix match"):
         fixed(nop, scores)
 
+    # the default: the processor surface raises inside the call, like the reference; the fused form defers
+    dflt = ConstrainedLogitsProcessor(fn, K, 3, None, eos)
+    dflt.count = 1
+    with pytest.raises(AssertionError, match="No valid tokens for prefix_ids"):
+        dflt(bad, scores)
+    dflt.count = 1
+    dflt.candidates(bad, scores)
+    with pytest.raises(AssertionError, match="No valid tokens for prefix_ids"):
+        dflt.reset()
+    with pytest.raises(ValueError, match="Failed to find a valid trie prefix match"):
+        FixedHintConstrainedLogitsProcessor(fn, K, 3, prefix, eos)(bad, scores)
+
     # lazy mode: the failure surfaces at reset() / count
     lazy = ConstrainedLogitsProcessor(fn, K, 3, None, eos, sync_errors=False)
     lazy.count = 1

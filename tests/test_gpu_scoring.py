@@ -262,3 +262,24 @@ def test_result_json_and_metrics_straight_from_beam_ids(tmp_path):
     assert all(abs(from_text[k] - want[k]) <= 1e-12 for k in want)
     saved = json.load(open(tmp_path / "run" / "metrics.json"))
     assert saved == {k: round(v, 4) for k, v in want.items()}
+
+
+def test_ragged_prediction_lists_and_numbers_beyond_32_bits_follow_the_reference():
+    """Edge cases recorded from the reference (tests/golden/make_golden_edge.py): compute_metrics on
+    records whose prediction lists differ in length -- cut-offs from the first sample, each sample
+    skipped for every k beyond its own list (evaluate.py:137-143, 168-170) -- and the text rewards on
+    numbers that do not fit int32 / int64 (the reference compares Python integers)."""
+    from genrec_amd.metrics import compute_metrics
+    from genrec_amd.rewards import ranking_reward as rr
+
+    _dev()
+    g = load_json_gz("scoring_edge.json.gz")
+    for name, case in g["metrics"].items():
+        got = compute_metrics(case["data"])
+        assert list(got) == list(case["metrics"]), name
+        for k, v in case["metrics"].items():
+            assert abs(got[k] - v) <= 1e-12, (name, k)
+    kw = dict(reward_model=[{"ground_truth": t} for t in g["gts"]])
+    assert rr.rule_reward(None, g["comps"], None, **kw) == g["rule"]
+    assert rr.get_ndcg_rule_reward(g["K"])(None, g["comps"], None, **kw) == pytest.approx(g["ndcg"], abs=1e-7)
+    assert rr.get_prefix_rule_reward(True)(None, g["comps"], None, **kw) == pytest.approx(g["prefix"], abs=1e-7)

@@ -163,6 +163,17 @@ def test_scoring_oracle_matches_reference_golden():
     assert oscore.ref_compute_metrics(g["metrics_data"]) == g["metrics"]
 
 
+def test_scoring_oracle_matches_reference_on_edge_cases():
+    """Ragged prediction lists and numbers beyond 32 bits, recorded from the reference by
+    tests/golden/make_golden_edge.py."""
+    g = load_json_gz("scoring_edge.json.gz")
+    for name, case in g["metrics"].items():
+        assert oscore.ref_compute_metrics(case["data"]) == case["metrics"], name
+    assert oscore.ref_rule_reward(g["comps"], g["gts"]) == g["rule"]
+    assert oscore.ref_prefix_reward(g["comps"], g["gts"]) == g["prefix"]
+    assert oscore.ref_ndcg_reward(g["comps"], g["gts"], g["K"]) == g["ndcg"]
+
+
 def test_docs_worked_examples():
     """docs/2026-03-13-genrec-rl-reward-forms.md:119,216-221,283-301,358-380,407-423 of the reference."""
     assert [round(w, 4) for w in oscore.ndcg_rank_weights(4)] == [-0.3904, -0.2463, -0.1952, -0.1681]
