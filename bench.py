@@ -151,53 +151,51 @@ class Rollout:
 
 
 def time_cpu_baseline(args, wl):
-    """The oracle (CPU restatement of the reference processor + HF beam step) on a bounded sample."""
+    """The oracle (CPU restatement of the reference processor + HF beam step) on the workload's own
+    row count: one generation (`levels` steps over all batch x beams rows), timed step by step."""
     import torch
 
     from oracle.beam import RefBeamSearch
     from oracle.processors import DictTrie, RefConstrainedLogitsProcessor, RefFixedHintConstrainedLogitsProcessor
 
-    groups = args.cpu_groups
+    groups = args.batch if args.cpu_groups <= 0 else min(args.cpu_groups, args.batch)
     K = args.beams
     trie = DictTrie(sorted(wl["trie"]))
     cls = RefFixedHintConstrainedLogitsProcessor if args.processor == "fixed_hint" else RefConstrainedLogitsProcessor
     proc = cls(trie.get, K, wl["pidx"], wl["suffix"], wl["tok"].eos_token_id)
     prompts = wl["prompts"][:groups].cpu().repeat_interleave(K, dim=0)
     V, levels = wl["V"], wl["levels"]
-    logits = [wl["logits"][d][: groups * K].float().cpu() for d in range(levels)]
-
-    def run(cores, budget_s):
-        torch.set_num_threads(cores)
-        t_total, n_steps = 0.0, 0
-        while t_total < budget_s or n_steps < levels:
-            state = RefBeamSearch(prompts, K, prompts.shape[1] + levels + 1, wl["tok"].eos_token_id,
-                                  wl["tok"].pad_token_id, 1.0, False)
-            if hasattr(proc, "reset"):
-                proc.reset()
-            for d in range(levels):
-                t0 = time.perf_counter()
-                flat = state.flat_running_sequences()
-                lp = torch.nn.functional.log_softmax(logits[d], dim=-1)  # HF normalises first (utils.py:3388)
-                lp = proc(flat, lp)
-                state.step(lp)
-                t_total += time.perf_counter() - t0
-                n_steps += 1
-        return n_steps * groups * K / t_total / (args.batch * K), n_steps, t_total
-
-    # the box's CPU share for one GPU is 16 cores; 8 is what the reference survey was timed on
+    # the box's CPU share for one GPU is 16 cores
     cores = min(16, os.cpu_count() or 1)
-    value, n_steps, t_total = run(cores, args.cpu_seconds)
-    value8, n8, t8 = run(min(8, cores), args.cpu_seconds / 2)
-    return {
-        "value": value,
+    torch.set_num_threads(cores)
+    t_total, n_steps = 0.0, 0
+    while n_steps < levels or (t_total < args.cpu_seconds and groups < args.batch):
+        state = RefBeamSearch(prompts, K, prompts.shape[1] + levels + 1, wl["tok"].eos_token_id,
+                              wl["tok"].pad_token_id, 1.0, False)
+        if hasattr(proc, "reset"):
+            proc.reset()
+        for d in range(levels):
+            x = wl["logits"][d][: groups * K].float().cpu()  # fp32 on the host, as HF hands them over (untimed)
+            t0 = time.perf_counter()
+            flat = state.flat_running_sequences()
+            lp = torch.nn.functional.log_softmax(x, dim=-1)  # HF normalises first (utils.py:3388)
+            lp = proc(flat, lp)
+            state.step(lp)
+            t_total += time.perf_counter() - t0
+            n_steps += 1
+            del x, lp
+    rows = groups * K
+    out = {
+        "value": n_steps / t_total * (rows / (args.batch * K)),
         "unit": "steps/s",
         "cores": cores,
         "kind": "port",
-        "sample": f"{n_steps} steps of {groups * K} rows (fp32 logits, V={V}) in {t_total:.1f}s; "
-                  f"scaled to steps of {args.batch * K} rows",
-        "value_at_8_cores": value8,
-        "sample_at_8_cores": f"{n8} steps of {groups * K} rows in {t8:.1f}s",
+        "sample": f"{n_steps} steps of {rows} rows (fp32 logits, V={V}) in {t_total:.1f}s"
+                  + ("" if rows == args.batch * K else f"; scaled to steps of {args.batch * K} rows"),
     }
+    if rows != args.batch * K:
+        out["value_extrapolated_from_rows"] = rows
+    return out
 
 
 def time_processor_surface(args, wl, device, calls=10):
@@ -285,6 +283,22 @@ def baseline_metric() -> str:
         return "constrained decode steps/sec (batch\u00d7beam=8192, V\u2248152k); % HBM roofline"
 
 
+KERNEL_SOURCES = ("genrec_amd/csrc/masked_logsoftmax.hip", "genrec_amd/csrc/lse_math.h", "genrec_amd/csrc/common.h",
+                  "genrec_amd/csrc/resolve.h", "include/genrec_hip.h")
+
+
+def kernel_sources_sha256() -> str:
+    """Fingerprint of the sources the streaming kernel is built from: counter figures recorded for one
+    version of the kernel are not reported for another."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for rel in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(rel.encode() + b"\0" + f.read() + b"\0")
+    return h.hexdigest()
+
+
 def recorded_traffic(args, alg_bytes):
     """HBM bytes per launch of the dominant kernel from hardware counters.
 
@@ -293,7 +307,8 @@ def recorded_traffic(args, alg_bytes):
     command, whose per-launch averages are kept in profiles/*_pmc_summary.json
     (FETCH_SIZE is in KiB and, on gfx950, counts half the bytes of a wide
     coalesced stream, hence the factor 2 applied there).  The recorded figure
-    only applies to the workload it was collected on; anything else reports null.
+    only applies to the workload and to the kernel sources (their SHA-256 is kept
+    in the summary) it was collected on; anything else reports null.
     """
     import glob
 
@@ -303,8 +318,10 @@ def recorded_traffic(args, alg_bytes):
     if not files:
         return None, None
     with open(files[-1]) as f:
-        rec = json.load(f)["masked_lsm_kernel_hbm_bytes_per_launch"]
-    if int(rec["algorithmic"]) != int(alg_bytes):
+        summary = json.load(f)
+    rec = summary["masked_lsm_kernel_hbm_bytes_per_launch"]
+    # counters taken on other kernel sources (or on another workload) say nothing about this build
+    if summary.get("kernel_sources_sha256") != kernel_sources_sha256() or int(rec["algorithmic"]) != int(alg_bytes):
         return None, None
     return float(rec["total"]), os.path.relpath(files[-1], ROOT)
 
@@ -323,7 +340,8 @@ def main() -> None:
     ap.add_argument("--processor", default="count", choices=["count", "fixed_hint"])
     ap.add_argument("--prompt-len", type=int, default=61)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--cpu-groups", type=int, default=16)
+    ap.add_argument("--cpu-groups", type=int, default=0,
+                    help="prompt groups of the CPU baseline sample (0: all of --batch, i.e. the real row count)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-processor-surface", action="store_true", help="skip the dense [R, V] mode measurement")
     ap.add_argument("--no-plan-ahead", action="store_true",
@@ -428,6 +446,7 @@ def main() -> None:
             "data": "synthetic",
             "config": {
                 "workload": f"{'C2: ' if (args.trie, args.processor, args.batch) == ('Instruments', 'count', 512) else ''}"
+                            f"{'C1 (3-level id2sid index): ' if args.trie == 'Industrial_and_Scientific' else ''}"
                             f"{args.trie} SID trie, {args.processor} processor, beam={args.beams}, "
                             f"batch={args.batch} per GPU (R={R} rows), V={wl['V']}, {args.dtype} logits N(0,16); "
                             f"fused step = row planning + masked log-softmax (compact candidates) + beam step; every "

@@ -43,6 +43,10 @@ def main():
     fetch = pmc["FETCH_SIZE"][key]["avg_kb"] * 1024 * 2
     write = pmc["WRITE_SIZE"][key]["avg_kb"] * 1024
     alg = b["roofline"]["algorithmic_bytes_per_launch"]
+    sys.path.insert(0, ROOT)
+    import bench
+
+    pmc["kernel_sources_sha256"] = bench.kernel_sources_sha256()
     pmc["masked_lsm_kernel_hbm_bytes_per_launch"] = {
         "read_corrected": fetch, "write": write, "total": fetch + write, "algorithmic": alg,
         "note": "FETCH_SIZE x 1024 x 2 (gfx950 reports exactly half the bytes of a 16-B-per-lane coalesced "
