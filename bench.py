@@ -92,7 +92,9 @@ class Rollout:
         self.R = args.batch * args.beams
         from genrec_amd.logit_processor import Candidates
 
-        self.cand = Candidates(self.R, max(wl["trie"].max_fanout, 1), device)
+        # a group keeps 2 x beams candidates per step, so rows hand over at most that many (their best)
+        self.keep = 0 if getattr(args, "no_keep_top", False) else wl["proc"].keep_top_for(2 * args.beams)
+        self.cand = Candidates(self.R, wl["proc"].candidate_width(2 * args.beams if self.keep else 0), device)
         self.scorer = SidRewardScorer(wl["tok"].code_table(wl["V"]), args.beams, device)
         self.weights = torch.tensor([1.0, 1.0], dtype=torch.float32, device=device)
         self.rpf = torch.empty((self.R, 2), dtype=torch.float32, device=device)
@@ -124,7 +126,8 @@ class Rollout:
                 self.score()
             self.new_generation()
         flat = self.state.flat_running_sequences()
-        wl["proc"].candidates_into(flat, wl["logits"][self.depth], self.cand)
+        wl["proc"].candidates_into(flat, wl["logits"][self.depth], self.cand, keep_top=self.keep,
+                                   row_bias=self.state.row_bias() if self.keep else None)
         # the beam kernel plans the next processor call, except after the last level of a generation
         planner = wl["proc"] if (self.plan_ahead and self.depth + 1 < wl["levels"]) else None
         self.state.step(self.cand, wl["V"], planner)
@@ -346,6 +349,8 @@ def main() -> None:
     ap.add_argument("--no-processor-surface", action="store_true", help="skip the dense [R, V] mode measurement")
     ap.add_argument("--no-plan-ahead", action="store_true",
                     help="let every processor call run its own row planning kernel (as under the plain HF loop)")
+    ap.add_argument("--no-keep-top", action="store_true",
+                    help="rows emit every allowed token instead of their 2 x beams best (A/B of the row truncation)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="leave the per-launch HIP events out")
     ap.add_argument("--time-every", type=int, default=4,
                     help="attach HIP events to every n-th launch of the streaming kernel in the timed region (an "

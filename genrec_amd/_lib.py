@@ -81,7 +81,8 @@ class GrxConstraint(C.Structure):
         ("repetition_penalty", C.c_float),
         ("penalty_skip", C.c_int32),
         ("assume_normalized", C.c_int32),
-        ("reserved", C.c_int32),
+        ("keep_top", C.c_int32),
+        ("row_bias", C.c_void_p),
     ]
 
 

@@ -156,6 +156,11 @@ class BeamSearchState:
     def is_sent_finished(self) -> torch.Tensor:
         return self.fin_done[self.cur].bool()
 
+    def row_bias(self) -> torch.Tensor:
+        """[B*K] running beam scores: what the next step adds to a row's log-probs before ranking
+        (``candidates_into(..., keep_top=state.n_keep, row_bias=state.row_bias())``)."""
+        return self.run_score[self.cur].view(-1)
+
     def flat_running_sequences(self) -> torch.Tensor:
         """[B*K, cur_len] view (row stride max_length) to hand to the processor."""
         return self.run_seq[self.cur].view(self.B * self.K, self.max_length)[:, : self.cur_len]
@@ -274,7 +279,9 @@ def constrained_beam_search(
                             first_step_shared=first_step_shared)
     from .logit_processor import Candidates
 
-    cmax = max(processor.trie.max_fanout, 1)
+    # a group keeps n_keep candidates, so no row needs to hand over more than its n_keep best
+    keep = processor.keep_top_for(state.n_keep)
+    cmax = processor.candidate_width(state.n_keep)
     cand = Candidates(state.B * num_beams, cmax, input_ids.device)
     step = 0
     next_parent = None
@@ -283,12 +290,12 @@ def constrained_beam_search(
             flat = state.prompt_rows()
             logits = logits_fn(step, flat, next_parent)
             first = Candidates(state.B, cmax, input_ids.device)
-            processor.candidates_into(flat, logits, first, one_row_per_group=True)
+            processor.candidates_into(flat, logits, first, one_row_per_group=True, keep_top=keep)
             res = state.step(first, logits.shape[-1], planner=processor, shared_rows=True)
         else:
             flat = state.flat_running_sequences()
             logits = logits_fn(step, flat, next_parent)
-            processor.candidates_into(flat, logits, cand)
+            processor.candidates_into(flat, logits, cand, keep_top=keep, row_bias=state.row_bias())
             res = state.step(cand, logits.shape[-1], planner=processor)
         next_parent = res.next_parent
         step += 1

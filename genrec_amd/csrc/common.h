@@ -94,6 +94,10 @@ struct grx_state {
     bool ahead_open;
 };
 
+// keep_top (grx_constraint): longest kept list, and the widest node whose children can be ranked in LDS
+#define BS_KEEP_CAP 512
+#define GRX_KEEP_TOP_MAX_FANOUT 1024
+
 #define GRX_NO_MATCH 0x7FFFFFFF
 #define GRX_NO_ERR 0xFFFFFFFFu
 

@@ -24,40 +24,6 @@
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-enum { OUT_COMPACT = 0, OUT_FULL_F32 = 1, OUT_FULL_SAME = 2 };
-
-struct MlsArgs {
-    const int32_t* tok;    // child tokens of the trie (CSR)
-    const int32_t* off;    // child offsets of the trie (CSR)
-    const grx_row_plan* plan;  // fixed-hint mode: [R] from the planning kernel of this call
-    grx_state_words* st;   // may be null (fixed-hint without error reporting)
-    int walk;              // count mode: every workgroup works out its row's node itself (pc, ids, T) ...
-    int bookkeep;          // ... and workgroup 0 records the call's counter / re-arms the next match word
-    PlanCtx pc;
-    int R;
-    const void* scores;
-    int64_t scores_stride;
-    int V;
-    int eos;
-    void* out;             // full modes
-    int64_t out_stride;
-    grx_cand* cand;        // compact mode: [R, cand_stride] rows of {token, logp} behind a {count, lse} header
-    int64_t cand_stride;
-    int cmax;
-    // Split rows (few rows): a row is streamed by S workgroups; the last one to
-    // finish merges the S partial (max, sum) pairs and emits the row.
-    // Repetition penalty (0: off) over the tokens of ids[r, pen_from:T).
-    float penalty;
-    int pen_from;
-    const int64_t* ids;
-    int64_t ids_stride;
-    int T;
-    int S;
-    int skip_stream;       // rows are log-softmax values already (log-sum-exp 0): gather only
-    int* split_count;      // [R] arrival counters, zero between calls
-    float2* split_part;    // [R * S] partial (max, sum)
-};
-
 static constexpr float kLog2e = 1.4426950408889634f;
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
@@ -173,13 +139,6 @@ template <> struct Elem<GRX_F16> {
     }
     static constexpr uint32_t kNegInfPacked = 0xFC00FC00u;
 };
-
-// Output element of a dense mode: fp32, or the input element type.
-template <int DT, int OUT>
-__device__ __forceinline__ auto to_out(float v) {
-    if constexpr (OUT == OUT_FULL_F32) return v;
-    else return Elem<DT>::from_float(v);
-}
 
 // ---- online softmax accumulator ---------------------------------------------
 // A thread's share of a row: m = largest element seen, s = sum of 2^(x * log2e + c) over the

@@ -17,6 +17,49 @@
 
 #include "lse_math.h"
 
+enum { OUT_COMPACT = 0, OUT_FULL_F32 = 1, OUT_FULL_SAME = 2 };
+
+struct MlsArgs {
+    const int32_t* tok;    // child tokens of the trie (CSR)
+    const int32_t* off;    // child offsets of the trie (CSR)
+    const grx_row_plan* plan;  // fixed-hint mode: [R] from the planning kernel of this call
+    grx_state_words* st;   // may be null (fixed-hint without error reporting)
+    int walk;              // count mode: every workgroup works out its row's node itself (pc, ids, T) ...
+    int bookkeep;          // ... and workgroup 0 records the call's counter / re-arms the next match word
+    PlanCtx pc;
+    int R;
+    const void* scores;
+    int64_t scores_stride;
+    int V;
+    int eos;
+    void* out;             // full modes
+    int64_t out_stride;
+    grx_cand* cand;        // compact mode: [R, cand_stride] rows of {token, logp} behind a {count, lse} header
+    int64_t cand_stride;
+    int cmax;
+    // Split rows (few rows): a row is streamed by S workgroups; the last one to
+    // finish merges the S partial (max, sum) pairs and emits the row.
+    // Repetition penalty (0: off) over the tokens of ids[r, pen_from:T).
+    float penalty;
+    int pen_from;
+    const int64_t* ids;
+    int64_t ids_stride;
+    int T;
+    int S;
+    int skip_stream;       // rows are log-softmax values already (log-sum-exp 0): gather only
+    int keep_top;          // compact mode, > 0: rows with more candidates keep their keep_top best, best first
+    const float* row_bias; // ... ranked by logp + row_bias[r] (null: 0), the sum the beam step ranks by
+    int* split_count;      // [R] arrival counters, zero between calls
+    float2* split_part;    // [R * S] partial (max, sum)
+};
+
+
+// Output element of a dense mode: fp32, or the input element type.
+template <int DT, int OUT>
+__device__ __forceinline__ auto to_out(float v) {
+    if constexpr (OUT == OUT_FULL_F32) return v;
+    else return Elem<DT>::from_float(v);
+}
 
 #ifdef MLS_STAMP
 // Diagnostic build only: phase timestamps (100 MHz counter) of the first 4096 workgroups.
@@ -83,7 +126,9 @@ __global__ __launch_bounds__(MLS_THREADS) void masked_lsm_kernel(MlsArgs a) {
     if (code < 0 && code != GRX_RES_EOS && tid == 0 && part == 0) {
         report_row_error(a.st, r, code == GRX_RES_NOMATCH ? GRX_ROWERR_NOMATCH : GRX_ROWERR_EMPTY);
     }
-    if (OUT == OUT_COMPACT && c_n > a.cmax) {
+    // compact rows keep either every candidate or, past keep_top of them, the keep_top best
+    const bool trunc = OUT == OUT_COMPACT && a.keep_top > 0 && c_n > a.keep_top;
+    if (OUT == OUT_COMPACT && (trunc ? a.keep_top : c_n) > a.cmax) {
         if (tid == 0 && part == 0) report_row_error(a.st, r, GRX_ROWERR_OVERFLOW);
         c_n = 0;
     }
@@ -306,6 +351,72 @@ __global__ __launch_bounds__(MLS_THREADS) void masked_lsm_kernel(MlsArgs a) {
         grx_cand* __restrict__ crow = a.cand + (int64_t)r * a.cand_stride;
         const int n_line = ((c_n + 1 + 15) / 16) * 16;
         static_assert(MLS_EARLY == 2, "the compact epilogue pairs two 8-byte entries per 16-byte store");
+        if (trunc && c_n > 0) {
+            // More candidates than the beam step can ever keep from one row: rank them here -- by
+            // (logp + row bias) descending, token ascending, the order the beam step uses -- and emit the
+            // keep_top best, best first.  Candidate i lives with thread (i + 1) / 2 (the two gathered up
+            // front) or, from i = 511 on, with thread (i - 511) mod 256.  The keys go through the LDS block
+            // of the penalty set, which nobody reads after the log-probs below are final.
+            constexpr int XTRA = (GRX_KEEP_TOP_MAX_FANOUT - (2 * MLS_THREADS - 1) + MLS_THREADS - 1) / MLS_THREADS;
+            static_assert(PEN_SLOTS * sizeof(int) >= GRX_KEEP_TOP_MAX_FANOUT * 4 + BS_KEEP_CAP * 8, "LDS block too small");
+            const int keep = a.keep_top;
+            const float bias = a.row_bias ? a.row_bias[r] : 0.f;
+            int m_idx[2 + XTRA], m_tok[2 + XTRA];
+            float m_lp[2 + XTRA];
+            uint32_t m_key[2 + XTRA];
+#pragma unroll
+            for (int k = 0; k < 2 + XTRA; ++k) {
+                const int i = k < 2 ? tid * 2 + k - 1 : (2 * MLS_THREADS - 1) + (k - 2) * MLS_THREADS + tid;
+                m_idx[k] = (i >= 0 && i < c_n) ? i : -1;
+                m_tok[k] = 0;
+                m_lp[k] = 0.f;
+                m_key[k] = 0;
+                if (m_idx[k] >= 0) {
+                    m_tok[k] = k < 2 ? e_tok[k] : a.tok[c_off + i];
+                    const float xm = (k < 2 ? e_val[k] : E::to_float(row[m_tok[k]])) - tot.m;
+                    m_lp[k] = final_logp(m_tok[k], xm);
+                    m_key[k] = float_to_ordered(m_lp[k] + bias);
+                }
+            }
+            __syncthreads();  // the penalty set has been consulted for the last time
+            uint32_t* const s_key = reinterpret_cast<uint32_t*>(s_pen);
+            grx_cand* const s_out = reinterpret_cast<grx_cand*>(s_pen + GRX_KEEP_TOP_MAX_FANOUT);
+#pragma unroll
+            for (int k = 0; k < 2 + XTRA; ++k)
+                if (m_idx[k] >= 0) s_key[m_idx[k]] = m_key[k];
+            __syncthreads();
+            int rank[2 + XTRA];
+#pragma unroll
+            for (int k = 0; k < 2 + XTRA; ++k) rank[k] = 0;
+            for (int j = 0; j < c_n; ++j) {
+                const uint32_t o = s_key[j];  // one address for the whole workgroup: a broadcast
+#pragma unroll
+                for (int k = 0; k < 2 + XTRA; ++k) rank[k] += (o > m_key[k] || (o == m_key[k] && j < m_idx[k])) ? 1 : 0;
+            }
+#pragma unroll
+            for (int k = 0; k < 2 + XTRA; ++k) {
+                if (m_idx[k] >= 0 && rank[k] < keep) {
+                    grx_cand v;
+                    v.x = m_tok[k];
+                    v.y = __float_as_int(m_lp[k]);
+                    s_out[rank[k]] = v;
+                }
+            }
+            __syncthreads();
+            const int n_kept_line = ((keep + 1 + 15) / 16) * 16;
+            for (int e = tid * 2; e < n_kept_line; e += MLS_THREADS * 2) {
+                grx_cand v0 = {0, 0}, v1 = {0, 0};
+                if (e == 0) {
+                    v0.x = keep;
+                    v0.y = __float_as_int(tot.m + log_s + lse2);
+                } else if (e - 1 < keep) {
+                    v0 = s_out[e - 1];
+                }
+                if (e < keep) v1 = s_out[e];
+                cand_store2(crow + e, v0, v1);
+            }
+            return;
+        }
         auto entry = [&](int e, int tokv, float xm) {  // compact entry e of this row
             grx_cand v = {0, 0};
             if (e == 0) {
@@ -543,6 +654,11 @@ static int run_step(const char* who, const grx_trie* trie, grx_state* state, con
         GRX_REQUIRE(rows->T - con->penalty_skip <= GRX_MAX_PENALTY_TOKENS, GRX_E_UNSUPPORTED,
                     "%s: repetition penalty over more than %d tokens per row", who, GRX_MAX_PENALTY_TOKENS);
     }
+    GRX_REQUIRE(con->keep_top >= 0 && con->keep_top <= BS_KEEP_CAP, GRX_E_INVALID, "%s: keep_top must be in [0, %d]", who,
+                BS_KEEP_CAP);
+    GRX_REQUIRE(con->keep_top == 0 || out_kind != OUT_COMPACT || trie->max_fanout <= GRX_KEEP_TOP_MAX_FANOUT,
+                GRX_E_UNSUPPORTED, "%s: keep_top serves tries of fan-out <= %d (this one: %d)", who,
+                GRX_KEEP_TOP_MAX_FANOUT, trie->max_fanout);
     // Nothing below this line fails on an argument: the call now counts and its kernels are enqueued.
     // phase 0: one small kernel works out the trie node of every row
     grx_row_plan* plan = rows->R > 0
@@ -572,6 +688,8 @@ static int run_step(const char* who, const grx_trie* trie, grx_state* state, con
     a.eos = con->eos_token_id;
     const bool vec = rows_16b_aligned(rows->scores, rows->scores_stride, dtype_size(rows->dtype)) && out_aligned;
     a.S = 1;
+    a.keep_top = out_kind == OUT_COMPACT ? con->keep_top : 0;
+    a.row_bias = a.keep_top > 0 ? con->row_bias : nullptr;
     a.skip_stream = con->assume_normalized;
     if (vec && !a.skip_stream) {
         const int S = grx_split_factor(rows->R, (int)(rows->V / (16 / dtype_size(rows->dtype))));

@@ -151,7 +151,10 @@ def constrained_generate(
     # reads B rows instead of B * K identical ones and the first beam step extends all beams from it.
     state = BeamSearchState(rows, K, T + max_new_tokens, eos, pad, length_penalty, early_stopping,
                             shared_prompt=True, planner=processor, first_step_shared=share_prefill)
-    cmax = max(processor.trie.max_fanout, 1)
+    # whole-logits steps hand over at most n_keep candidates per row (all a group can keep); the sliced
+    # step emits every allowed token
+    keep = 0 if lm_head_slice else processor.keep_top_for(state.n_keep)
+    cmax = processor.candidate_width(state.n_keep if keep else 0)
     cand = Candidates(B * K, cmax, dev)
 
     # ---- prefill (only the last position's logits are needed: the LM head is the widest matmul)
@@ -190,7 +193,8 @@ def constrained_generate(
         if sliced is not None:
             sliced.candidates_into(processor, ids, x, buf, one_row_per_group=one_row_per_group)
         else:
-            processor.candidates_into(ids, x, buf, one_row_per_group=one_row_per_group)
+            processor.candidates_into(ids, x, buf, one_row_per_group=one_row_per_group, keep_top=keep,
+                                      row_bias=None if one_row_per_group else state.row_bias())
 
     step = 0
     while True:

@@ -430,8 +430,28 @@ class _TrieConstrainedBase(LogitsProcessor):
         self.candidates_into(input_ids, scores, cand)
         return cand
 
-    def candidates_into(self, input_ids, scores, cand: "Candidates", one_row_per_group: bool = False) -> None:
+    KEEP_TOP_MAX, KEEP_TOP_MAX_FANOUT = 512, 1024  # limits of the kernel's per-row ranking
+
+    def keep_top_for(self, n_keep: int) -> int:
+        """The ``keep_top`` to pass for a beam step that keeps ``n_keep`` candidates per group: ``n_keep``
+        when the kernel can rank this trie's rows (0 = no truncation otherwise)."""
+        ok = 0 < n_keep <= self.KEEP_TOP_MAX and self.trie.max_fanout <= self.KEEP_TOP_MAX_FANOUT
+        return int(n_keep) if ok else 0
+
+    def candidate_width(self, n_keep: int = 0) -> int:
+        """Entries a candidate row needs: the widest node of the trie, or ``n_keep`` if rows are cut there."""
+        width = max(self.trie.max_fanout, 1)
+        keep = self.keep_top_for(n_keep)
+        return min(width, keep) if keep else width
+
+    def candidates_into(self, input_ids, scores, cand: "Candidates", one_row_per_group: bool = False,
+                        keep_top: int = 0, row_bias: Optional[torch.Tensor] = None) -> None:
         """``candidates`` writing into a caller-owned buffer (no allocation per step).
+
+        ``keep_top`` > 0: rows with more allowed tokens emit only their ``keep_top`` best, best first,
+        ranked by ``logp + row_bias[row]`` (fp32 [rows]; the running beam scores) descending, token
+        ascending -- the order the beam step ranks by, which never takes more than its ``n_keep`` from one
+        row: with ``keep_top = n_keep`` the search is unchanged and the candidate traffic shrinks.
 
         ``one_row_per_group``: the rows are prompts, one per beam group, instead of ``num_beams``
         identical copies of each (the first step of a search: the copies would give identical
@@ -440,11 +460,17 @@ class _TrieConstrainedBase(LogitsProcessor):
         rows, ids_keep, scores_keep = self._rows(input_ids, scores, whole_groups=not one_row_per_group)
         index = self._device_index(scores_keep)
         assert cand.rows == rows.R and cand.buf.device == scores_keep.device
+        if row_bias is not None:
+            _lib.require_cuda(row_bias, "row_bias")
+            if row_bias.dtype != torch.float32 or row_bias.numel() != rows.R or not row_bias.is_contiguous():
+                raise ValueError("row_bias must be a contiguous float32 tensor with one value per row")
         self._take_planned(rows, ids_keep)
         with torch.cuda.device(index):
             st = self._state(index)
             ws = self._workspace(index, rows.R)
             con = self._constraint()
+            con.keep_top = int(keep_top)
+            con.row_bias = row_bias.data_ptr() if (row_bias is not None and keep_top) else None
             _lib.check(
                 _lib.lib().grx_constrained_candidates(
                     self.trie.device_handle(scores_keep.device),

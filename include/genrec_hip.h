@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define GRX_ABI_VERSION 7
+#define GRX_ABI_VERSION 8
 
 #if defined(GRX_BUILDING)
 #define GRX_API __attribute__((visibility("default")))
@@ -142,7 +142,17 @@ typedef struct grx_constraint {
      * one write pass instead of a read and a write.  Not combinable with the fused
      * repetition penalty. */
     int32_t assume_normalized;
-    int32_t reserved;
+    /* Compact form only (grx_constrained_candidates*): 0 = emit every allowed token of a row, tokens
+     * ascending.  k > 0: a row with more than k allowed tokens emits only its k best, best first --
+     * ranked by (logp + row_bias[r]) descending, token ascending, which is how grx_beam_step ranks
+     * the candidates of a beam -- and its header count is k.  A beam step that keeps n_keep
+     * candidates per group never takes more than n_keep from one row, so with k = n_keep and
+     * row_bias = the running beam scores (grx_beam_step_args.run_score_in; NULL when every row's
+     * score is the same, as on the shared first step) its results are unchanged while candidate
+     * buffers, their writes and the beam step's reads shrink from max-fanout to n_keep entries per
+     * row.  k <= 512; tries whose widest node has more than 1024 children are refused. */
+    int32_t keep_top;
+    const float* row_bias;    /* device fp32 [R] or NULL; read only when keep_top > 0 */
 } grx_constraint;
 #define GRX_MAX_PENALTY_TOKENS 1536
 
