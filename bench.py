@@ -94,7 +94,8 @@ class Rollout:
 
         # a group keeps 2 x beams candidates per step, so rows hand over at most that many (their best)
         self.keep = 0 if getattr(args, "no_keep_top", False) else wl["proc"].keep_top_for(2 * args.beams)
-        self.cand = Candidates(self.R, wl["proc"].candidate_width(2 * args.beams if self.keep else 0), device)
+        width = wl["proc"].candidate_width(2 * args.beams if self.keep else 0)
+        self.cand = Candidates(self.R, max(width, getattr(args, "cand_width", 0)), device)
         self.scorer = SidRewardScorer(wl["tok"].code_table(wl["V"]), args.beams, device)
         self.weights = torch.tensor([1.0, 1.0], dtype=torch.float32, device=device)
         self.rpf = torch.empty((self.R, 2), dtype=torch.float32, device=device)
@@ -351,6 +352,7 @@ def main() -> None:
                     help="let every processor call run its own row planning kernel (as under the plain HF loop)")
     ap.add_argument("--no-keep-top", action="store_true",
                     help="rows emit every allowed token instead of their 2 x beams best (A/B of the row truncation)")
+    ap.add_argument("--cand-width", type=int, default=0, help="candidate entries per row, at least (tuning)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="leave the per-launch HIP events out")
     ap.add_argument("--time-every", type=int, default=4,
                     help="attach HIP events to every n-th launch of the streaming kernel in the timed region (an "

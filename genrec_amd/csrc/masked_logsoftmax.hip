@@ -47,7 +47,7 @@ struct MlsArgs {
     int T;
     int S;
     int skip_stream;       // rows are log-softmax values already (log-sum-exp 0): gather only
-    int keep_top;          // compact mode, > 0: rows with more candidates keep their keep_top best, best first
+    int keep_top;          // compact mode, > 0: rows with more candidates keep only their keep_top best
     const float* row_bias; // ... ranked by logp + row_bias[r] (null: 0), the sum the beam step ranks by
     int* split_count;      // [R] arrival counters, zero between calls
     float2* split_part;    // [R * S] partial (max, sum)
@@ -71,6 +71,57 @@ extern "C" __attribute__((visibility("default"))) int grx_debug_read_mls_stamps(
 #else
 #define MSTAMP(n) do { } while (0)
 #endif
+
+// ---- the keep_top best of a row ---------------------------------------------------
+// One wave picks the `keep` largest of the n keys in s_key (n <= 64 * Q; ties: lower index first) and
+// stores {token, logp} of each at entry 1 + its slot of the candidate row, slots in no particular
+// order.  Lane l holds keys l, l + 64, ...: the keep-th largest key is built bit by bit from ballot
+// counts (32 rounds of Q compares, nothing leaves the registers), keys above it take the first slots
+// in candidate order, keys equal to it the remaining ones.
+template <int Q>
+__device__ __forceinline__ void select_top(const uint32_t* s_key, const float* s_lp, const int32_t* __restrict__ toks,
+                                           int n, int keep, int lane, grx_cand* __restrict__ crow) {
+    uint32_t key[Q];
+    bool in[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        in[q] = lane + q * GRX_WAVE < n;
+        key[q] = in[q] ? s_key[lane + q * GRX_WAVE] : 0u;
+    }
+    uint32_t T = 0;
+    for (int bit = 31; bit >= 0; --bit) {
+        const uint32_t trial = T | (1u << bit);
+        int cnt = 0;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) cnt += __popcll(__ballot(in[q] && key[q] >= trial));
+        if (cnt >= keep) T = trial;
+    }
+    int n_gt = 0;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) n_gt += __popcll(__ballot(in[q] && key[q] > T));
+    const unsigned long long below = (1ull << lane) - 1ull;
+    int gt_seen = 0, eq_seen = 0;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const int i = lane + q * GRX_WAVE;
+        const bool gt = in[q] && key[q] > T, eq = in[q] && key[q] == T;
+        const unsigned long long m_gt = __ballot(gt), m_eq = __ballot(eq);
+        int pos = -1;
+        if (gt) pos = gt_seen + __popcll(m_gt & below);
+        if (eq) {
+            const int er = eq_seen + __popcll(m_eq & below);
+            if (n_gt + er < keep) pos = n_gt + er;
+        }
+        if (pos >= 0) {
+            grx_cand v;
+            v.x = toks[i];
+            v.y = __float_as_int(s_lp[i]);
+            cand_store(crow + 1 + pos, v);
+        }
+        gt_seen += __popcll(m_gt);
+        eq_seen += __popcll(m_eq);
+    }
+}
 
 // ---- the kernel --------------------------------------------------------------
 // DT: element type of the logits.  OUT: OUT_*.  VEC: rows (and, for the full
@@ -127,7 +178,9 @@ __global__ __launch_bounds__(MLS_THREADS) void masked_lsm_kernel(MlsArgs a) {
         report_row_error(a.st, r, code == GRX_RES_NOMATCH ? GRX_ROWERR_NOMATCH : GRX_ROWERR_EMPTY);
     }
     // compact rows keep either every candidate or, past keep_top of them, the keep_top best
-    const bool trunc = OUT == OUT_COMPACT && a.keep_top > 0 && c_n > a.keep_top;
+    // (only rows that shed at least GRX_KEEP_TOP_SLACK entries: the selection holds the workgroup's slot
+    // for about a microsecond, which a few saved entries do not pay for)
+    const bool trunc = OUT == OUT_COMPACT && a.keep_top > 0 && c_n > a.keep_top + GRX_KEEP_TOP_SLACK;
     if (OUT == OUT_COMPACT && (trunc ? a.keep_top : c_n) > a.cmax) {
         if (tid == 0 && part == 0) report_row_error(a.st, r, GRX_ROWERR_OVERFLOW);
         c_n = 0;
@@ -352,69 +405,75 @@ __global__ __launch_bounds__(MLS_THREADS) void masked_lsm_kernel(MlsArgs a) {
         const int n_line = ((c_n + 1 + 15) / 16) * 16;
         static_assert(MLS_EARLY == 2, "the compact epilogue pairs two 8-byte entries per 16-byte store");
         if (trunc && c_n > 0) {
-            // More candidates than the beam step can ever keep from one row: rank them here -- by
-            // (logp + row bias) descending, token ascending, the order the beam step uses -- and emit the
-            // keep_top best, best first.  Candidate i lives with thread (i + 1) / 2 (the two gathered up
-            // front) or, from i = 511 on, with thread (i - 511) mod 256.  The keys go through the LDS block
-            // of the penalty set, which nobody reads after the log-probs below are final.
-            constexpr int XTRA = (GRX_KEEP_TOP_MAX_FANOUT - (2 * MLS_THREADS - 1) + MLS_THREADS - 1) / MLS_THREADS;
-            static_assert(PEN_SLOTS * sizeof(int) >= GRX_KEEP_TOP_MAX_FANOUT * 4 + BS_KEEP_CAP * 8, "LDS block too small");
+            // More candidates than the beam step can ever keep from one row: hand over only the keep_top
+            // best by (logp + row bias) descending, token ascending -- the order the beam step ranks by.
+            // Every thread finishes the log-probs of its candidates (candidate i lives with thread
+            // (i + 1) / 2, or from i = 511 on with thread (i - 511) mod 256) and leaves them, with their
+            // sort keys, in the LDS block of the penalty set, which nobody reads once the log-probs are
+            // final.  Wave 0 alone then selects: the keep_top-th largest key is built bit by bit from
+            // ballot counts (keys in registers, 32 rounds, no barriers), keys above it are kept, keys equal
+            // to it in candidate order until keep_top entries are placed.  The kept entries come out in no
+            // particular order: the beam step does not need one.
+            constexpr int KPL = GRX_KEEP_TOP_MAX_FANOUT / GRX_WAVE;  // keys per lane of wave 0, at most
+            static_assert(PEN_SLOTS * sizeof(int) >= GRX_KEEP_TOP_MAX_FANOUT * 8, "LDS block too small");
+            uint32_t* const s_key = reinterpret_cast<uint32_t*>(s_pen);
+            float* const s_lp = reinterpret_cast<float*>(s_pen + GRX_KEEP_TOP_MAX_FANOUT);
             const int keep = a.keep_top;
             const float bias = a.row_bias ? a.row_bias[r] : 0.f;
-            int m_idx[2 + XTRA], m_tok[2 + XTRA];
-            float m_lp[2 + XTRA];
-            uint32_t m_key[2 + XTRA];
+            float lp0 = 0.f, lp1 = 0.f;
+            const int i0 = tid * 2 - 1, i1 = tid * 2;
+            if (i0 >= 0 && i0 < c_n) lp0 = final_logp(e_tok[0], e_val[0] - tot.m);
+            if (i1 < c_n) lp1 = final_logp(e_tok[1], e_val[1] - tot.m);
+            constexpr int FIRST = 2 * MLS_THREADS - 1;  // candidates gathered up front
+            constexpr int XTRA = (GRX_KEEP_TOP_MAX_FANOUT - FIRST + MLS_THREADS - 1) / MLS_THREADS;
+            float lpx[XTRA];
+            if (c_n > FIRST) {  // wider nodes: the rest is gathered now
 #pragma unroll
-            for (int k = 0; k < 2 + XTRA; ++k) {
-                const int i = k < 2 ? tid * 2 + k - 1 : (2 * MLS_THREADS - 1) + (k - 2) * MLS_THREADS + tid;
-                m_idx[k] = (i >= 0 && i < c_n) ? i : -1;
-                m_tok[k] = 0;
-                m_lp[k] = 0.f;
-                m_key[k] = 0;
-                if (m_idx[k] >= 0) {
-                    m_tok[k] = k < 2 ? e_tok[k] : a.tok[c_off + i];
-                    const float xm = (k < 2 ? e_val[k] : E::to_float(row[m_tok[k]])) - tot.m;
-                    m_lp[k] = final_logp(m_tok[k], xm);
-                    m_key[k] = float_to_ordered(m_lp[k] + bias);
+                for (int k = 0; k < XTRA; ++k) {
+                    const int i = FIRST + k * MLS_THREADS + tid;
+                    lpx[k] = 0.f;
+                    if (i < c_n) {
+                        const int tokv = a.tok[c_off + i];
+                        lpx[k] = final_logp(tokv, E::to_float(row[tokv]) - tot.m);
+                    }
                 }
             }
             __syncthreads();  // the penalty set has been consulted for the last time
-            uint32_t* const s_key = reinterpret_cast<uint32_t*>(s_pen);
-            grx_cand* const s_out = reinterpret_cast<grx_cand*>(s_pen + GRX_KEEP_TOP_MAX_FANOUT);
-#pragma unroll
-            for (int k = 0; k < 2 + XTRA; ++k)
-                if (m_idx[k] >= 0) s_key[m_idx[k]] = m_key[k];
-            __syncthreads();
-            int rank[2 + XTRA];
-#pragma unroll
-            for (int k = 0; k < 2 + XTRA; ++k) rank[k] = 0;
-            for (int j = 0; j < c_n; ++j) {
-                const uint32_t o = s_key[j];  // one address for the whole workgroup: a broadcast
-#pragma unroll
-                for (int k = 0; k < 2 + XTRA; ++k) rank[k] += (o > m_key[k] || (o == m_key[k] && j < m_idx[k])) ? 1 : 0;
+            if (i0 >= 0 && i0 < c_n) {
+                s_lp[i0] = lp0;
+                s_key[i0] = float_to_ordered(lp0 + bias);
             }
+            if (i1 < c_n) {
+                s_lp[i1] = lp1;
+                s_key[i1] = float_to_ordered(lp1 + bias);
+            }
+            if (c_n > FIRST) {
 #pragma unroll
-            for (int k = 0; k < 2 + XTRA; ++k) {
-                if (m_idx[k] >= 0 && rank[k] < keep) {
-                    grx_cand v;
-                    v.x = m_tok[k];
-                    v.y = __float_as_int(m_lp[k]);
-                    s_out[rank[k]] = v;
+                for (int k = 0; k < XTRA; ++k) {
+                    const int i = FIRST + k * MLS_THREADS + tid;
+                    if (i < c_n) {
+                        s_lp[i] = lpx[k];
+                        s_key[i] = float_to_ordered(lpx[k] + bias);
+                    }
                 }
             }
             __syncthreads();
+            if (tid >= GRX_WAVE) return;
+            const int lane = tid;
+            const int q_n = (c_n + GRX_WAVE - 1) / GRX_WAVE;
+            if (q_n <= 2) select_top<2>(s_key, s_lp, a.tok + c_off, c_n, keep, lane, crow);
+            else if (q_n <= 4) select_top<4>(s_key, s_lp, a.tok + c_off, c_n, keep, lane, crow);
+            else if (q_n <= 8) select_top<8>(s_key, s_lp, a.tok + c_off, c_n, keep, lane, crow);
+            else select_top<KPL>(s_key, s_lp, a.tok + c_off, c_n, keep, lane, crow);
             const int n_kept_line = ((keep + 1 + 15) / 16) * 16;
-            for (int e = tid * 2; e < n_kept_line; e += MLS_THREADS * 2) {
-                grx_cand v0 = {0, 0}, v1 = {0, 0};
-                if (e == 0) {
-                    v0.x = keep;
-                    v0.y = __float_as_int(tot.m + log_s + lse2);
-                } else if (e - 1 < keep) {
-                    v0 = s_out[e - 1];
-                }
-                if (e < keep) v1 = s_out[e];
-                cand_store2(crow + e, v0, v1);
+            if (lane == 0) {
+                grx_cand h;
+                h.x = keep;
+                h.y = __float_as_int(tot.m + log_s + lse2);
+                cand_store(crow, h);
             }
+            const grx_cand zero = {0, 0};
+            for (int e = keep + 1 + lane; e < n_kept_line; e += GRX_WAVE) cand_store(crow + e, zero);
             return;
         }
         auto entry = [&](int e, int tokv, float xm) {  // compact entry e of this row

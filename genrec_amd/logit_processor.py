@@ -430,7 +430,8 @@ class _TrieConstrainedBase(LogitsProcessor):
         self.candidates_into(input_ids, scores, cand)
         return cand
 
-    KEEP_TOP_MAX, KEEP_TOP_MAX_FANOUT = 512, 1024  # limits of the kernel's per-row ranking
+    KEEP_TOP_MAX, KEEP_TOP_MAX_FANOUT = 512, 1024  # limits of the kernel's per-row selection
+    KEEP_TOP_SLACK = 64                              # rows up to keep_top + this many entries are emitted whole
 
     def keep_top_for(self, n_keep: int) -> int:
         """The ``keep_top`` to pass for a beam step that keeps ``n_keep`` candidates per group: ``n_keep``
@@ -442,14 +443,14 @@ class _TrieConstrainedBase(LogitsProcessor):
         """Entries a candidate row needs: the widest node of the trie, or ``n_keep`` if rows are cut there."""
         width = max(self.trie.max_fanout, 1)
         keep = self.keep_top_for(n_keep)
-        return min(width, keep) if keep else width
+        return min(width, keep + self.KEEP_TOP_SLACK) if keep else width
 
     def candidates_into(self, input_ids, scores, cand: "Candidates", one_row_per_group: bool = False,
                         keep_top: int = 0, row_bias: Optional[torch.Tensor] = None) -> None:
         """``candidates`` writing into a caller-owned buffer (no allocation per step).
 
-        ``keep_top`` > 0: rows with more allowed tokens emit only their ``keep_top`` best, best first,
-        ranked by ``logp + row_bias[row]`` (fp32 [rows]; the running beam scores) descending, token
+        ``keep_top`` > 0: rows with more than ``keep_top + KEEP_TOP_SLACK`` allowed tokens emit only their
+        ``keep_top`` best (in no particular order), ranked by ``logp + row_bias[row]`` (fp32 [rows]; the running beam scores) descending, token
         ascending -- the order the beam step ranks by, which never takes more than its ``n_keep`` from one
         row: with ``keep_top = n_keep`` the search is unchanged and the candidate traffic shrinks.
 

@@ -143,14 +143,17 @@ typedef struct grx_constraint {
      * repetition penalty. */
     int32_t assume_normalized;
     /* Compact form only (grx_constrained_candidates*): 0 = emit every allowed token of a row, tokens
-     * ascending.  k > 0: a row with more than k allowed tokens emits only its k best, best first --
-     * ranked by (logp + row_bias[r]) descending, token ascending, which is how grx_beam_step ranks
-     * the candidates of a beam -- and its header count is k.  A beam step that keeps n_keep
-     * candidates per group never takes more than n_keep from one row, so with k = n_keep and
-     * row_bias = the running beam scores (grx_beam_step_args.run_score_in; NULL when every row's
-     * score is the same, as on the shared first step) its results are unchanged while candidate
-     * buffers, their writes and the beam step's reads shrink from max-fanout to n_keep entries per
-     * row.  k <= 512; tries whose widest node has more than 1024 children are refused. */
+     * ascending.  k > 0: a row with more than k + GRX_KEEP_TOP_SLACK allowed tokens emits only its k
+     * best, in no particular order -- ranked by (logp + row_bias[r]) descending, token ascending,
+     * which is how grx_beam_step ranks the candidates of a beam -- and its header count is k; rows
+     * with fewer are emitted whole (shedding a handful of entries costs more than writing them).
+     * A beam step that keeps n_keep candidates per group never takes more than n_keep from one
+     * row, so with k = n_keep and row_bias = the running beam scores
+     * (grx_beam_step_args.run_score_in; NULL when every row's score is the same, as on the shared
+     * first step) its results are unchanged while candidate rows never exceed
+     * k + GRX_KEEP_TOP_SLACK entries: buffers (cmax), their writes and the beam step's reads shrink
+     * accordingly.  k <= 512; tries whose widest node has more than 1024 children are refused. */
+#define GRX_KEEP_TOP_SLACK 64
     int32_t keep_top;
     const float* row_bias;    /* device fp32 [R] or NULL; read only when keep_top > 0 */
 } grx_constraint;

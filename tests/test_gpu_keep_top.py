@@ -12,6 +12,7 @@ import torch
 from test_gpu_processors import _dev
 
 pytestmark = pytest.mark.gpu
+SLACK = 64  # GRX_KEEP_TOP_SLACK: rows that would shed fewer entries are emitted whole
 
 
 def _wide_trie(fanouts, seed=0, eos=2, prefix=(11, 12, 13), first_token=100):
@@ -30,7 +31,8 @@ def _wide_trie(fanouts, seed=0, eos=2, prefix=(11, 12, 13), first_token=100):
 
 
 def _expected(full, bias, keep):
-    """Per row: (tokens, logp bits) of the `keep` best by (fp32(logp + bias) desc, token asc)."""
+    """Per row: (tokens, logp) of the `keep` best by (fp32(logp + bias) desc, token asc); rows of at most
+    `keep` candidates whole, tokens ascending."""
     count = full.count.cpu().numpy()
     tok = full.tokens.cpu().numpy()
     lp = full.logp.cpu().numpy()
@@ -38,7 +40,7 @@ def _expected(full, bias, keep):
     for r in range(len(count)):
         n = int(count[r])
         t, v = tok[r, :n], lp[r, :n]
-        if n <= keep:
+        if n <= keep + SLACK:
             out.append((t, v))
             continue
         s = (v + np.float32(bias[r])).astype(np.float32)
@@ -47,8 +49,16 @@ def _expected(full, bias, keep):
     return out
 
 
+def _same_entries(got_t, got_v, want_t, want_v, r):
+    """The same (token, logp bits) pairs; rows that were cut come in no particular order."""
+    g = np.argsort(got_t, kind="stable")
+    w = np.argsort(want_t, kind="stable")
+    assert np.array_equal(got_t[g], want_t[w]), r
+    assert np.array_equal(got_v[g].view(np.int32), want_v[w].view(np.int32)), r
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("fan,keep,rows", [(162, 32, 64), (700, 32, 48), (700, 100, 16), (1024, 512, 8), (40, 64, 32)])
+@pytest.mark.parametrize("fan,keep,rows", [(162, 32, 64), (700, 32, 48), (700, 100, 16), (1024, 512, 8), (40, 64, 32), (97, 32, 32), (96, 32, 32)])
 def test_rows_are_cut_to_their_best_in_beam_order(dtype, fan, keep, rows):
     from genrec_amd.logit_processor import Candidates, ConstrainedLogitsProcessor
     from genrec_amd.trie import FlatTrie, create_prefix_allowed_tokens_fn
@@ -69,7 +79,8 @@ def test_rows_are_cut_to_their_best_in_beam_order(dtype, fan, keep, rows):
     proc.count = 0
     full = proc.candidates(ids, scores)
     assert int(full.count.max()) == fan
-    cut = Candidates(rows, min(fan, keep), dev)
+    cut = Candidates(rows, proc.candidate_width(keep), dev)
+    assert cut.cmax == min(fan, keep + SLACK)
     cut.buf.fill_(-5)
     proc.count = 0
     proc.candidates_into(ids, scores, cut, keep_top=keep, row_bias=bias)
@@ -78,8 +89,7 @@ def test_rows_are_cut_to_their_best_in_beam_order(dtype, fan, keep, rows):
     got_n, got_t, got_v = cut.count.cpu().numpy(), cut.tokens.cpu().numpy(), cut.logp.cpu().numpy()
     for r, (t, v) in enumerate(want):
         assert got_n[r] == len(t)
-        assert np.array_equal(got_t[r, : len(t)], t), r
-        assert np.array_equal(got_v[r, : len(t)].view(np.int32), v.view(np.int32)), r
+        _same_entries(got_t[r, : len(t)], got_v[r, : len(t)], t, v, r)
     # whole lines: zero padding behind the kept entries
     n_line = ((cut.count + 1 + 15) // 16) * 16
     e = torch.arange(cut.stride, device=dev)[None, :]
@@ -89,7 +99,7 @@ def test_rows_are_cut_to_their_best_in_beam_order(dtype, fan, keep, rows):
     proc.count = 0
     proc.candidates_into(ids, scores, cut, keep_top=keep)
     for r, (t, v) in enumerate(_expected(full, np.zeros(rows, dtype=np.float32), keep)):
-        assert np.array_equal(cut.tokens[r, : len(t)].cpu().numpy(), t), r
+        _same_entries(cut.tokens[r, : len(t)].cpu().numpy(), cut.logp[r, : len(t)].cpu().numpy(), t, v, r)
     proc.check_errors()
 
 
@@ -112,12 +122,12 @@ def test_cut_rows_under_a_repetition_penalty_are_ranked_by_the_penalised_values(
     proc.count = 0
     full = proc.candidates(ids, scores)
     bias = torch.randn(rows, device=dev)
-    cut = Candidates(rows, keep, dev)
+    cut = Candidates(rows, proc.candidate_width(keep), dev)
     proc.count = 0
     proc.candidates_into(ids, scores, cut, keep_top=keep, row_bias=bias)
     for r, (t, v) in enumerate(_expected(full, bias.cpu().numpy(), keep)):
-        assert np.array_equal(cut.tokens[r, : len(t)].cpu().numpy(), t), r
-        assert np.array_equal(cut.logp[r, : len(t)].cpu().numpy().view(np.int32), v.view(np.int32)), r
+        assert int(cut.count[r]) == len(t) == keep
+        _same_entries(cut.tokens[r, : len(t)].cpu().numpy(), cut.logp[r, : len(t)].cpu().numpy(), t, v, r)
     proc.check_errors()
 
 
@@ -145,7 +155,7 @@ def test_a_search_over_cut_rows_equals_the_search_over_whole_rows(K):
         state = BeamSearchState(prompts.repeat_interleave(K, dim=0), K, prompts.shape[1] + 5, eos, 0)
         keep = state.n_keep if cut else 0
         cand = Candidates(B * K, proc.candidate_width(state.n_keep if cut else 0), dev)
-        assert (cand.cmax == state.n_keep) == cut
+        assert cand.cmax == (min(120, state.n_keep + SLACK) if cut else 120)
         trace = []
         for step in range(4):
             proc.candidates_into(state.flat_running_sequences(), table[step], cand, keep_top=keep,
