@@ -28,7 +28,9 @@ _SCALE = {"none": 0, "group": 1, "batch": 2}
 
 def gather_rows(t: torch.Tensor) -> torch.Tensor:
     """All-gather along dim 0 (``accelerate.utils.gather``); identity without a process group."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
+        return t
+    if dist.get_world_size() == 1 and not _single_rank_collectives():
         return t
     t = t.contiguous()
     shape = (dist.get_world_size() * t.shape[0],) + tuple(t.shape[1:])
@@ -145,9 +147,19 @@ class RolloutAdvantages:
         return tuple(self)[i]
 
 
+def _single_rank_collectives() -> bool:
+    """GENREC_AMD_SINGLE_RANK_COLLECTIVES=1: issue the collective even in a process group of one rank
+    (lets a one-GPU box run the RCCL code path itself; off by default, where one rank gathers nothing)."""
+    import os
+
+    return os.environ.get("GENREC_AMD_SINGLE_RANK_COLLECTIVES", "0") not in ("", "0")
+
+
 def _start_gather(t: torch.Tensor):
     """Begin ``gather_rows(t)`` without waiting: (work, output tensor, device to move it to or None)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
+        return None, t, None
+    if dist.get_world_size() == 1 and not _single_rank_collectives():
         return None, t, None
     t = t.contiguous()
     shape = (dist.get_world_size() * t.shape[0],) + tuple(t.shape[1:])
@@ -189,6 +201,6 @@ def rollout_advantages(local_rewards_per_func: torch.Tensor, reward_weights: tor
     rewards, adv, mean, std = group_advantages(local_rewards_per_func, reward_weights, num_generations,
                                                scale_rewards, eps)
     res = RolloutAdvantages(adv, (rewards, mean, std), pending, reward_weights, num_generations, scale_rewards, eps)
-    if pending[0] is None and pending[2] is None:  # one process: the local rows are all rows
+    if pending[0] is None and pending[2] is None and pending[1] is local_rewards_per_func:  # one process, no collective
         res._global = (rewards, adv, mean, std)
     return res

@@ -133,12 +133,20 @@ __global__ __launch_bounds__(MLS_THREADS) void masked_lsm_kernel(MlsArgs a) {
     typedef typename E::T T;
     constexpr int EPV = VEC ? E::kPerVec : 1;  // elements per access
     __shared__ float s_m[MLS_WAVES], s_s[MLS_WAVES];
+#ifdef MLS_LDS_PAD
+    // occupancy experiment: extra LDS per workgroup lowers the number of workgroups a CU holds
+    __shared__ int s_pad[MLS_LDS_PAD / 4];
+    if (a.R < 0) s_pad[threadIdx.x] = a.V;
+#endif
 
     const int r = SPLIT ? (int)blockIdx.x / a.S : (int)blockIdx.x;
     const int part = SPLIT ? (int)blockIdx.x - r * a.S : 0;
     const int tid = threadIdx.x;
     const T* __restrict__ row = reinterpret_cast<const T*>(a.scores) + (int64_t)r * a.scores_stride;
     MSTAMP(0);
+#ifdef MLS_LDS_PAD
+    if (a.R < 0 && s_pad[(tid * 7) % (MLS_LDS_PAD / 4)] == 3) return;
+#endif
 
     // The first batch of the stream is issued before anything else: the plan
     // lookup below is a scalar load, which does not queue behind it.

@@ -21,3 +21,15 @@ def test_two_ranks_get_the_single_process_values():
     run = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=200)
     assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-4000:]
     assert "exchange rank 0 ok" in run.stdout and "exchange rank 1 ok" in run.stdout
+
+
+@pytest.mark.gpu
+def test_the_rccl_code_path_runs_with_one_rank():
+    """backend "nccl" (RCCL) on the box's one GPU: the asynchronous device all-gather of the exchange
+    step and the device-side reduction, issued with a single participant."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", "29619", os.path.join(ROOT, "tests", "workers", "rccl_single_rank.py")]
+    run = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=200)
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-4000:]
+    assert "rccl single rank ok" in run.stdout
