@@ -135,16 +135,16 @@ class Rollout:
         self.depth += 1
 
     def score(self):
-        from genrec_amd.advantage import rollout_advantages
+        from genrec_amd.advantage import rollout_score
 
         st = self.state
         gen = st.sequences[:, :, st.prompt_len : st.cur_len].reshape(self.R, -1)
-        self.scorer(gen, self.wl["gt"], want=("rule", "ndcg"), out=self.rpf)
         # the advantages of the local groups are ready in stream order; the all-gather behind the logged
         # global statistics runs beside the next generation and is collected one rollout later
         if self.exchange is not None:
             self.gathered = self.exchange.gathered_rewards_per_func()
-        self.exchange = rollout_advantages(self.rpf, self.weights, self.args.beams, "group")
+        self.exchange = rollout_score(self.scorer, gen, self.wl["gt"], self.weights, "group", want=("rule", "ndcg"),
+                                      out=self.rpf)
         self.adv = self.exchange.local_advantages
 
     def finish(self):

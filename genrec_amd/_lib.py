@@ -50,6 +50,7 @@ EXPORTED_SYMBOLS = (
     "grx_beam_init",
     "grx_sid_rewards",
     "grx_sid_rewards_tokens",
+    "grx_rollout_score_tokens",
     "grx_hit_ranks",
     "grx_group_advantage",
     "grx_group_normalize_tokenwise",
@@ -244,6 +245,9 @@ def _declare(lib: C.CDLL) -> None:
     lib.grx_sid_rewards.argtypes = [vp, vp, i32, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, i32, vp]
     lib.grx_sid_rewards_tokens.restype = C.c_int
     lib.grx_sid_rewards_tokens.argtypes = [vp, i64, i32, vp, i64, i32, vp, i32, i32, i32, i32, vp, vp, vp, vp, i32, vp]
+    lib.grx_rollout_score_tokens.restype = C.c_int
+    lib.grx_rollout_score_tokens.argtypes = [vp, i64, i32, vp, i64, i32, vp, i32, i32, i32, i32, vp, vp, i32, vp, vp, i32,
+                                             f32, vp, vp, vp, vp, vp]
     lib.grx_hit_ranks.restype = C.c_int
     lib.grx_hit_ranks.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp]
     lib.grx_group_advantage.restype = C.c_int

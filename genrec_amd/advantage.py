@@ -204,3 +204,23 @@ def rollout_advantages(local_rewards_per_func: torch.Tensor, reward_weights: tor
     if pending[0] is None and pending[2] is None and pending[1] is local_rewards_per_func:  # one process, no collective
         res._global = (rewards, adv, mean, std)
     return res
+
+
+def rollout_score(scorer, completion_ids: torch.Tensor, gt_ids: torch.Tensor, reward_weights: torch.Tensor,
+                  scale_rewards: str = "group", hint_ids: Optional[torch.Tensor] = None, want=("rule", "ndcg"),
+                  out: Optional[torch.Tensor] = None, eps: float = 1e-4) -> RolloutAdvantages:
+    """Scoring and exchange of a rollout shard: rewards of the local completions (``scorer``: a
+    ``SidRewardScorer``), local advantages, and the all-gather of the reward matrix started beside
+    them -- one kernel launch where ``scale_rewards`` allows it ("group", "none"), else rewards,
+    gather and ``rollout_advantages`` in sequence.  Returns a :class:`RolloutAdvantages`."""
+    if scale_rewards == "batch":
+        cols = scorer(completion_ids, gt_ids, hint_ids, want=want, out=out)
+        rpf = out if out is not None else torch.stack([cols[k] for k in want], dim=1)
+        return rollout_advantages(rpf, reward_weights, scorer.num_beams, scale_rewards, eps=eps)
+    rpf, (rewards, adv, mean, std) = scorer.score_with_advantages(completion_ids, gt_ids, reward_weights,
+                                                                  scale_rewards, hint_ids, want, out, eps)
+    pending = _start_gather(rpf)
+    res = RolloutAdvantages(adv, (rewards, mean, std), pending, reward_weights, scorer.num_beams, scale_rewards, eps)
+    if pending[0] is None and pending[2] is None and pending[1] is rpf:
+        res._global = (rewards, adv, mean, std)
+    return res

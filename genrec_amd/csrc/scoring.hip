@@ -3,6 +3,7 @@
 // logit stream; these kernels exist so that rollout scoring stays on the device
 // and in stream order behind the beam step.
 #include <math.h>
+#include <string.h>
 
 #include "common.h"
 
@@ -18,6 +19,13 @@ struct RewardArgs {
     int R, K, rows_per_block, prefix_normalize;
     const float* ndcg_w;
     float* rule_out; float* prefix_out; float* ndcg_out; int out_stride;
+    // Optional second half (grx_rollout_score_tokens): the weighted reward of every row and its
+    // group-relative advantage, from the values just computed -- what grx_group_advantage would
+    // read back from the reward matrix.  n_cols == 0: off.
+    int n_cols; int col_kind[3];     // kind of reward column c: 0 rule, 1 prefix, 2 ndcg
+    const float* adv_w;              // device [n_cols] reward weights
+    int scale; float eps;            // 0: none, 1: group std
+    float* rewards; float* adv; float* gmean; float* gstd;
 };
 
 // WIDE: rows are int64 token ids mapped through the code table; otherwise int32 codes.
@@ -61,23 +69,53 @@ __global__ __launch_bounds__(SC_THREADS) void sid_rewards_kernel(RewardArgs a) {
     }
     s_exact[t] = exact ? 1 : 0;
     __syncthreads();
-    if (!active) return;
-    const int64_t o = (int64_t)r * a.out_stride;
-    if (a.rule_out) a.rule_out[o] = exact ? 1.0f : 0.0f;
-    if (a.prefix_out) {
-        float v = 0.0f;
-        if (ng > 0) v = a.prefix_normalize ? (float)((double)matched / (double)ng) : (float)matched;
-        a.prefix_out[o] = v;
-    }
-    if (a.ndcg_out) {
-        const int g0 = (t / a.K) * a.K;              // first row of the group inside the block
-        const int64_t r0 = (int64_t)blockIdx.x * a.rows_per_block + g0;
-        if (r0 + a.K <= a.R) {                      // rows of an incomplete trailing group get no value
-            bool any = false;
-            for (int k = 0; k < a.K; ++k) any = any || s_exact[g0 + k];
-            a.ndcg_out[o] = (any && !exact) ? a.ndcg_w[t - g0] : 0.0f;
+    const int g0 = (t / a.K) * a.K;                  // first row of the group inside the block
+    float v_rule = 0.0f, v_prefix = 0.0f, v_ndcg = 0.0f;
+    if (active) {
+        const int64_t o = (int64_t)r * a.out_stride;
+        v_rule = exact ? 1.0f : 0.0f;
+        if (a.rule_out) a.rule_out[o] = v_rule;
+        if (ng > 0) v_prefix = a.prefix_normalize ? (float)((double)matched / (double)ng) : (float)matched;
+        if (a.prefix_out) a.prefix_out[o] = v_prefix;
+        if (a.ndcg_out) {
+            const int64_t r0 = (int64_t)blockIdx.x * a.rows_per_block + g0;
+            if (r0 + a.K <= a.R) {                  // rows of an incomplete trailing group get no value
+                bool any = false;
+                for (int k = 0; k < a.K; ++k) any = any || s_exact[g0 + k];
+                v_ndcg = (any && !exact) ? a.ndcg_w[t - g0] : 0.0f;
+                a.ndcg_out[o] = v_ndcg;
+            }
         }
     }
+    if (a.n_cols == 0) return;  // uniform
+    // weighted reward (nansum over the columns in their order) and the group statistics, as
+    // group_advantage_kernel forms them from the stored matrix
+    __shared__ float s_rew[SC_THREADS];
+    float rew = 0.0f;
+    for (int c = 0; c < a.n_cols; ++c) {
+        const float val = a.col_kind[c] == 0 ? v_rule : (a.col_kind[c] == 1 ? v_prefix : v_ndcg);
+        const float v = val * a.adv_w[c];
+        rew += (v != v) ? 0.0f : v;
+    }
+    s_rew[t] = active ? rew : 0.0f;
+    __syncthreads();
+    if (!active) return;
+    double sum = 0.0;
+    for (int k = 0; k < a.K; ++k) sum += (double)s_rew[g0 + k];
+    const double mean_d = sum / (double)a.K;
+    double q = 0.0;
+    for (int k = 0; k < a.K; ++k) {
+        const double dlt = (double)s_rew[g0 + k] - mean_d;
+        q += dlt * dlt;
+    }
+    const float mean = (float)mean_d;
+    const float sd = (float)sqrt(q / (double)(a.K - 1));
+    float adv = rew - mean;
+    if (a.scale != 0) adv = adv / (sd + a.eps);
+    if (a.rewards) a.rewards[r] = rew;
+    if (a.adv) a.adv[r] = adv;
+    if (a.gmean) a.gmean[r] = mean;
+    if (a.gstd) a.gstd[r] = sd;
 }
 
 static int launch_rewards(const char* who, RewardArgs& a, bool wide, void* stream) {
@@ -104,6 +142,7 @@ extern "C" int grx_sid_rewards(const int32_t* pred, const int32_t* pred_len, int
                                const float* ndcg_weights, float* rule_out, float* prefix_out, float* ndcg_out,
                                int32_t out_stride, void* stream) {
     RewardArgs a;
+    memset(&a, 0, sizeof(a));
     a.pred = pred; a.pred_len = pred_len; a.Lp = Lp; a.pred_stride = Lp;
     a.gt = gt; a.gt_len = gt_len; a.Lg = Lg; a.gt_stride = Lg;
     a.table = nullptr; a.table_size = 0;
@@ -119,12 +158,51 @@ extern "C" int grx_sid_rewards_tokens(const int64_t* pred_tok, int64_t pred_stri
                                       void* stream) {
     GRX_REQUIRE(code_table != nullptr && table_size > 0, GRX_E_INVALID, "grx_sid_rewards_tokens: empty code table");
     RewardArgs a;
+    memset(&a, 0, sizeof(a));
     a.pred = pred_tok; a.pred_len = nullptr; a.Lp = Lp; a.pred_stride = pred_stride;
     a.gt = gt_tok; a.gt_len = nullptr; a.Lg = Lg; a.gt_stride = gt_stride;
     a.table = code_table; a.table_size = table_size;
     a.R = R; a.K = K; a.prefix_normalize = prefix_normalize; a.ndcg_w = ndcg_weights;
     a.rule_out = rule_out; a.prefix_out = prefix_out; a.ndcg_out = ndcg_out; a.out_stride = out_stride;
     return launch_rewards("grx_sid_rewards_tokens", a, true, stream);
+}
+
+extern "C" int grx_rollout_score_tokens(const int64_t* pred_tok, int64_t pred_stride, int32_t Lp, const int64_t* gt_tok,
+                                        int64_t gt_stride, int32_t Lg, const int32_t* code_table, int32_t table_size,
+                                        int32_t R, int32_t K, int32_t prefix_normalize, const float* ndcg_weights,
+                                        float* rewards_per_func, int32_t n_funcs, const int32_t* func_kinds,
+                                        const float* reward_weights, int32_t scale, float eps, float* rewards,
+                                        float* advantages, float* group_mean, float* group_std, void* stream) {
+    const char* who = "grx_rollout_score_tokens";
+    GRX_REQUIRE(code_table != nullptr && table_size > 0, GRX_E_INVALID, "%s: empty code table", who);
+    GRX_REQUIRE(n_funcs >= 1 && n_funcs <= 3 && func_kinds != nullptr, GRX_E_INVALID, "%s: 1 to 3 reward columns", who);
+    GRX_REQUIRE(scale == 0 || scale == 1, GRX_E_UNSUPPORTED,
+                "%s: scale must be 0 (none) or 1 (group); the batch std needs every rank's rows (grx_group_advantage)",
+                who);
+    GRX_REQUIRE(K >= 1 && R >= 0 && R % K == 0, GRX_E_INVALID, "%s: %d rows do not split into groups of %d", who, R, K);
+    GRX_REQUIRE(R == 0 || (rewards_per_func != nullptr && reward_weights != nullptr), GRX_E_INVALID, "%s: null buffer",
+                who);
+    RewardArgs a;
+    memset(&a, 0, sizeof(a));
+    a.pred = pred_tok; a.Lp = Lp; a.pred_stride = pred_stride;
+    a.gt = gt_tok; a.Lg = Lg; a.gt_stride = gt_stride;
+    a.table = code_table; a.table_size = table_size;
+    a.R = R; a.K = K; a.prefix_normalize = prefix_normalize; a.ndcg_w = ndcg_weights;
+    a.out_stride = n_funcs;
+    int seen = 0;
+    for (int c = 0; c < n_funcs; ++c) {
+        const int kind = func_kinds[c];
+        GRX_REQUIRE(kind >= 0 && kind <= 2 && !(seen & (1 << kind)), GRX_E_INVALID,
+                    "%s: reward kinds must be distinct values of 0 (rule), 1 (prefix), 2 (ndcg)", who);
+        seen |= 1 << kind;
+        a.col_kind[c] = kind;
+        (kind == 0 ? a.rule_out : (kind == 1 ? a.prefix_out : a.ndcg_out)) = rewards_per_func + c;
+    }
+    a.n_cols = n_funcs;
+    a.adv_w = reward_weights;
+    a.scale = scale; a.eps = eps;
+    a.rewards = rewards; a.adv = advantages; a.gmean = group_mean; a.gstd = group_std;
+    return launch_rewards(who, a, true, stream);
 }
 
 // ------------------------------------------------------------ hit ranks ---

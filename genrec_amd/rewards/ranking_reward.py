@@ -273,3 +273,45 @@ class SidRewardScorer:
 
         return score_token_rows(rows(full), rows(gt_ids), self.table, self.num_beams, self.prefix_normalize, want,
                                 self.ndcg_weights, out=out)
+
+    _KIND = {"rule": 0, "prefix": 1, "ndcg": 2}
+
+    def score_with_advantages(self, completion_ids: torch.Tensor, gt_ids: torch.Tensor, reward_weights: torch.Tensor,
+                              scale_rewards: str = "group", hint_ids: Optional[torch.Tensor] = None,
+                              want=("rule", "ndcg"), out: Optional[torch.Tensor] = None, eps: float = 1e-4):
+        """One launch for a rollout shard's scoring: the reward columns of ``__call__`` (into ``out``
+        [R, len(want)]) plus ``(rewards, advantages, group_mean, std)`` of the rows, equal bit for bit to
+        ``group_advantages(out, reward_weights, num_beams, scale_rewards)`` -- for ``scale_rewards`` "group"
+        or "none", which need no other rank's rows.  Returns ``(out, (rewards, advantages, mean, std))``."""
+        if scale_rewards not in ("group", "none"):
+            raise ValueError("score_with_advantages serves scale_rewards 'group' and 'none'; 'batch' needs the "
+                             "rewards of every rank (rollout_advantages)")
+        full = completion_ids if hint_ids is None else torch.cat([hint_ids.to(completion_ids.device), completion_ids], 1)
+        full = full.to(device=self.device, dtype=torch.int64)
+        gt = gt_ids.to(device=self.device, dtype=torch.int64)
+        full = full if full.shape[1] == 0 or full.stride(1) == 1 else full.contiguous()
+        gt = gt if gt.shape[1] == 0 or gt.stride(1) == 1 else gt.contiguous()
+        R, n = full.shape[0], len(want)
+        if out is None:
+            out = torch.empty((R, n), dtype=torch.float32, device=self.device)
+        assert out.shape == (R, n) and out.dtype == torch.float32 and out.is_contiguous()
+        w = reward_weights.to(device=self.device, dtype=torch.float32).contiguous()
+        assert w.numel() == n
+        kinds = (C.c_int32 * n)(*[self._KIND[k] for k in want])
+        stats = [torch.empty(R, dtype=torch.float32, device=self.device) for _ in range(4)]
+
+        def stride(t):
+            return t.stride(0) if t.shape[0] > 1 else max(t.shape[1], 1)
+
+        index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        with torch.cuda.device(index):
+            _lib.check(
+                _lib.lib().grx_rollout_score_tokens(
+                    full.data_ptr(), stride(full), full.shape[1], gt.data_ptr(), stride(gt), gt.shape[1],
+                    self.table.data_ptr(), self.table.shape[0], R, self.num_beams, 1 if self.prefix_normalize else 0,
+                    self.ndcg_weights.data_ptr(), out.data_ptr(), n, kinds, w.data_ptr(),
+                    1 if scale_rewards == "group" else 0, float(eps), stats[0].data_ptr(), stats[1].data_ptr(),
+                    stats[2].data_ptr(), stats[3].data_ptr(), _lib.current_stream_ptr(self.device),
+                )
+            )
+        return out, tuple(stats)

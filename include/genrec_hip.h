@@ -458,6 +458,23 @@ GRX_API int grx_sid_rewards_tokens(const int64_t* pred_tok, int64_t pred_stride,
                                    void* stream);
 
 /*
+ * Rollout scoring in one launch: the rewards of grx_sid_rewards_tokens written as the columns of
+ * rewards_per_func (device fp32 [R, n_funcs]; func_kinds, host int32 [n_funcs], names the reward of
+ * each column: 0 rule, 1 prefix, 2 ndcg, each at most once) and, from the same values, what
+ * grx_group_advantage(rewards_per_func, reward_weights, R, n_funcs, K, scale, eps, ...) would
+ * compute -- bit for bit -- for scale 0 ("none") or 1 ("group").  Groups never straddle ranks
+ * (the rollout shards whole prompt groups), so these are the local rows' final advantages
+ * (fixed_hint_grpo_trainer.py:383-408); the all-gather of rewards_per_func that the reference
+ * runs first only feeds logging and scale "batch".  R must be a multiple of K.
+ */
+GRX_API int grx_rollout_score_tokens(const int64_t* pred_tok, int64_t pred_stride, int32_t Lp, const int64_t* gt_tok,
+                                     int64_t gt_stride, int32_t Lg, const int32_t* code_table, int32_t table_size,
+                                     int32_t R, int32_t K, int32_t prefix_normalize, const float* ndcg_weights,
+                                     float* rewards_per_func, int32_t n_funcs, const int32_t* func_kinds,
+                                     const float* reward_weights, int32_t scale, float eps, float* rewards,
+                                     float* advantages, float* group_mean, float* group_std, void* stream);
+
+/*
  * HR@k / NDCG@k support: rank of the first beam equal to the target
  * (evaluate.py:162-166).  beams [n, n_beam, L] and target [n, L] are device
  * int32 code rows (a beam equals the target when all L codes match).

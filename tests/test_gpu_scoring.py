@@ -283,3 +283,40 @@ def test_ragged_prediction_lists_and_numbers_beyond_32_bits_follow_the_reference
     assert rr.rule_reward(None, g["comps"], None, **kw) == g["rule"]
     assert rr.get_ndcg_rule_reward(g["K"])(None, g["comps"], None, **kw) == pytest.approx(g["ndcg"], abs=1e-7)
     assert rr.get_prefix_rule_reward(True)(None, g["comps"], None, **kw) == pytest.approx(g["prefix"], abs=1e-7)
+
+
+@pytest.mark.parametrize("K,want", [(16, ("rule", "ndcg")), (4, ("ndcg", "rule", "prefix")), (50, ("prefix",))])
+def test_one_launch_scoring_equals_rewards_then_advantages(K, want):
+    """grx_rollout_score_tokens: the reward columns and the local advantages of a rollout shard in one
+    kernel, bit for bit what the reward kernel followed by the advantage kernel produce."""
+    from genrec_amd.advantage import group_advantages, rollout_score
+    from genrec_amd.rewards.ranking_reward import SidRewardScorer
+
+    dev = _dev()
+    g = torch.Generator().manual_seed(K)
+    G, L = 37, 4
+    table = torch.full((700,), -1, dtype=torch.int32)
+    table[100:700] = torch.arange(600, dtype=torch.int32) % 41
+    gt = torch.randint(100, 700, (G, L), generator=g).repeat_interleave(K, dim=0)
+    comp = torch.randint(100, 700, (G * K, L + 1), generator=g)
+    comp[:, L] = 5  # EOS-like token without a code
+    hit = torch.rand(G * K, generator=g) < 0.25
+    comp[hit, :L] = gt[hit]
+    comp[K : 2 * K, :L] = gt[K : 2 * K]  # zero-variance group
+    w = torch.rand(len(want), generator=g).to(dev)
+    scorer = SidRewardScorer(table.numpy(), K, dev)
+    for scale in ("group", "none"):
+        cols = scorer(comp.to(dev), gt.to(dev), want=want)
+        rpf = torch.stack([cols[k] for k in want], dim=1).contiguous()
+        ref = group_advantages(rpf, w, K, scale)
+        res = rollout_score(scorer, comp.to(dev), gt.to(dev), w, scale, want=want)
+        assert torch.equal(res.gathered_rewards_per_func(), rpf)
+        assert torch.equal(res.local_advantages, ref[1]) and torch.equal(res.local_rewards, ref[0])
+        assert torch.equal(res.local_group_mean, ref[2]) and torch.equal(res.local_std, ref[3])
+        for a, b in zip(res.wait_global(), ref):
+            assert torch.equal(a, b)
+    res = rollout_score(scorer, comp.to(dev), gt.to(dev), w, "batch", want=want)  # falls back to the two-step path
+    ref = group_advantages(rpf, w, K, "batch")
+    assert torch.equal(res.local_advantages, ref[1])
+    with pytest.raises(ValueError):
+        scorer.score_with_advantages(comp.to(dev), gt.to(dev), w, "batch", want=want)
