@@ -99,8 +99,12 @@ __global__ __launch_bounds__(BS_THREADS) void beam_step_kernel(grx_beam_step_arg
     STAMP(0);
 
     // ---- phase A: every global read the step needs is issued before the first wait.
-    // Thread t prefetches column t of the first BS_PREFETCH beams (coalesced rows).
+    // Thread t prefetches one entry of each of the first BS_PREFETCH beams: entry (t - 37 u) mod 256 of
+    // beam u (coalesced, rotated rows).  The rotation spreads short rows over all threads, so that the
+    // per-lane maxima below stay informative when every row holds only a few candidates: unrotated, rows
+    // of c < n_keep entries would leave all but c lanes empty and nothing could be cut.
     grx_cand pre[BS_PREFETCH];
+    auto pre_col = [&](int u) { return (tid - 37 * u) & (BS_THREADS - 1); };
     // candidate row of beam k: g_cand + k * bstride (every beam reads the group's one row when they are shared)
     const int64_t bstride = a.cand_shared ? 0 : a.cand_stride;
     const grx_cand* __restrict__ g_cand = a.cand + (a.cand_shared ? (int64_t)b : row0) * a.cand_stride;
@@ -108,7 +112,7 @@ __global__ __launch_bounds__(BS_THREADS) void beam_step_kernel(grx_beam_step_arg
 #pragma unroll
         for (int u = 0; u < BS_PREFETCH; ++u) {
             // entries past a beam's count hold stale values; they are masked below
-            pre[u] = g_cand[(u < K && tid < cmax) ? (int64_t)u * bstride + 1 + tid : 0];
+            pre[u] = g_cand[(u < K && pre_col(u) < cmax) ? (int64_t)u * bstride + 1 + pre_col(u) : 0];
         }
     }
     for (int k = tid; k < K; k += BS_THREADS) {
@@ -166,13 +170,13 @@ __global__ __launch_bounds__(BS_THREADS) void beam_step_kernel(grx_beam_step_arg
     // reach) leaves a few dozen survivors; they are ranked against each other.
     bool selected = false;
     if (d.reg_keys) {
-        // K <= BS_PREFETCH beams of at most BS_THREADS candidates, n_keep <= 64: thread t holds column t
+        // K <= BS_PREFETCH beams of at most BS_THREADS candidates, n_keep <= 64: thread t holds one entry
         // of every beam.  64 partition maxima (lane-wise over the four waves) give the threshold.
         unsigned long long rk[BS_PREFETCH];
         unsigned long long tmax = 0;
 #pragma unroll
         for (int u = 0; u < BS_PREFETCH; ++u) {
-            rk[u] = (u < K && tid < cmax) ? key_at(u, tid, __int_as_float(pre[u].y), pre[u].x) : 0ull;
+            rk[u] = (u < K && pre_col(u) < cmax) ? key_at(u, pre_col(u), __int_as_float(pre[u].y), pre[u].x) : 0ull;
             tmax = rk[u] > tmax ? rk[u] : tmax;
         }
         s_tmax[tid] = tmax;
