@@ -7,7 +7,10 @@
  *                     and argument validation that fails before any device work
  *   abi_client gpu    one constrained decoding step on device 0 (trie upload,
  *                     count-based compact candidates, beam step), checked against
- *                     a float64 computation in this file
+ *                     a float64 computation in this file; the same candidates once
+ *                     more through the entry point that allocates nothing (byte
+ *                     for byte) and through the step over column slices (tokens
+ *                     equal, log-probs within 1e-5)
  *
  * Prints one "key=value" line per fact and "OK" last; exit status 0 on success.
  */
@@ -48,6 +51,11 @@ static int host_checks(void) {
     printf("sizeof_grx_beam_step_args=%zu\n", sizeof(grx_beam_step_args));
     printf("sizeof_grx_beam_init_args=%zu\n", sizeof(grx_beam_init_args));
     printf("sizeof_grx_cand=%zu\n", sizeof(grx_cand));
+    printf("sizeof_grx_chunk=%zu\n", sizeof(grx_chunk));
+    printf("noalloc_max_rows=%d\n", (int)grx_noalloc_max_rows());
+    CHECK(grx_noalloc_max_rows() == GRX_NOALLOC_MAX_ROWS, "library and header disagree on the scratch size");
+    CHECK(grx_chunk_parts(8192, 8192, GRX_BF16) == 1 && grx_chunk_parts(16, 65536, GRX_BF16) > 1,
+          "rows alone fill the GPU at 8192 rows; few rows are shared by several waves");
     printf("candidate_stride_242=%lld\n", (long long)grx_candidate_stride(242));
     printf("workspace_bytes_8192=%zu\n", grx_workspace_bytes(8192));
     CHECK(grx_candidate_stride(15) == 16 && grx_candidate_stride(16) == 32, "candidate stride rule");
@@ -184,6 +192,79 @@ static int gpu_checks(void) {
         }
         printf("max_abs_logp_error=%.3g\n", worst);
         CHECK(worst <= 1e-5, "log-probs within 1e-5 of the float64 log-softmax");
+    }
+
+    /* the same call without a workspace: byte-identical candidate rows */
+    {
+        grx_cand* h_again = (grx_cand*)malloc(sizeof(grx_cand) * NR * (size_t)stride);
+        void* d_again;
+        CHECK(hipMalloc(&d_again, sizeof(grx_cand) * NR * (size_t)stride) == 0, "hipMalloc");
+        CHECK(hipMemcpy(d_again, d_cand, sizeof(grx_cand) * NR * (size_t)stride, 3) == 0, "device copy");
+        CHECK(hipMemset(d_again, 0xEE, sizeof(grx_cand) * 8) == 0, "scribble");
+        CHECK(grx_state_set_count(state, 0, NULL) == GRX_OK, "grx_state_set_count");
+        CHECK(grx_constrained_candidates_noalloc(trie, state, &rows, &con, (grx_cand*)d_again, stride, NCMAX, NULL) == GRX_OK,
+              "grx_constrained_candidates_noalloc");
+        CHECK(hipMemcpy(h_again, d_again, sizeof(grx_cand) * NR * (size_t)stride, 2) == 0, "download");
+        for (r = 0; r < NR; ++r)
+            CHECK(memcmp(h_again + (size_t)r * stride, h_cand + (size_t)r * stride, sizeof(grx_cand) * 16) == 0,
+                  "the entry point that allocates nothing returns the same rows");
+        printf("noalloc_rows_identical=%d\n", NR);
+
+        /* and over two column slices of the logits, copied out as [NR, width] blocks */
+        {
+            const int cut = 2048;  /* tokens 100..300 in the first slice, 4000 in the second */
+            const int widths[2] = {cut, NV - cut};
+            float* h_slice = (float*)malloc(sizeof(float) * NR * (size_t)(NV - cut));
+            void *d_slice, *d_part;
+            grx_chunk ch;
+            double worst = 0.0;
+            int c;
+            CHECK(hipMalloc(&d_slice, sizeof(float) * NR * (size_t)(NV - cut)) == 0 &&
+                      hipMalloc(&d_part, sizeof(float) * 2 * NR * 8) == 0,
+                  "hipMalloc slices");
+            CHECK(hipMemset(d_again, 0xEE, sizeof(grx_cand) * NR * (size_t)stride) == 0, "scribble");
+            CHECK(grx_state_set_count(state, 0, NULL) == GRX_OK, "grx_state_set_count");
+            memset(&ch, 0, sizeof(ch));
+            ch.v_total = NV; ch.n_slots = 0;
+            for (c = 0; c < 2; ++c) ch.n_slots += grx_chunk_parts(NR, widths[c], GRX_F32);
+            CHECK(ch.n_slots <= 8, "partial buffer sized for 8 slots");
+            for (c = 0; c < 2; ++c) {
+                grx_rows part = rows;
+                const int begin = c == 0 ? 0 : cut;
+                for (r = 0; r < NR; ++r)
+                    memcpy(h_slice + (size_t)r * widths[c], h_logits + (size_t)r * NV + begin, sizeof(float) * widths[c]);
+                CHECK(hipDeviceSynchronize() == 0, "the previous slice has been consumed");
+                CHECK(hipMemcpy(d_slice, h_slice, sizeof(float) * NR * (size_t)widths[c], 1) == 0, "upload slice");
+                part.scores = d_slice; part.scores_stride = widths[c]; part.V = widths[c];
+                ch.v_begin = begin; ch.first = c == 0; ch.parts = grx_chunk_parts(NR, widths[c], GRX_F32);
+                CHECK(grx_constrained_partial(trie, state, &part, &con, &ch, (float*)d_part, (grx_cand*)d_again, stride, NCMAX,
+                                              d_ws, ws_bytes, NULL) == GRX_OK,
+                      "grx_constrained_partial");
+                ch.slot += ch.parts;
+            }
+            CHECK(grx_constrained_finish(NR, ch.n_slots, (const float*)d_part, (grx_cand*)d_again, stride, NCMAX, d_ws,
+                                         ws_bytes, NULL) == GRX_OK,
+                  "grx_constrained_finish");
+            CHECK(grx_state_read(state, st, NULL) == GRX_OK && st[0] == 1 && st[1] == GRX_ROWERR_NONE,
+                  "the sliced step counts as one processor call");
+            CHECK(hipMemcpy(h_again, d_again, sizeof(grx_cand) * NR * (size_t)stride, 2) == 0, "download");
+            for (r = 0; r < NR; ++r)
+                for (i = 0; i < 16; ++i) {
+                    const grx_cand a = h_again[(size_t)r * stride + i], w = h_cand[(size_t)r * stride + i];
+                    float fa, fw;
+                    memcpy(&fa, &a.y, 4);
+                    memcpy(&fw, &w.y, 4);
+                    CHECK(a.x == w.x, "sliced step: same counts, tokens and padding");
+                    if (i <= 4) worst = fabs((double)fa - (double)fw) > worst ? fabs((double)fa - (double)fw) : worst;
+                    else CHECK(a.y == 0, "zero padding");
+                }
+            printf("sliced_max_abs_logp_difference=%.3g\n", worst);
+            CHECK(worst <= 1e-5, "sliced log-probs within 1e-5 of the whole-row call");
+            hipFree(d_slice); hipFree(d_part);
+            free(h_slice);
+        }
+        hipFree(d_again);
+        free(h_again);
     }
 
     /* the beam step over those candidates: at step 0 only beam 0 of a group is live */

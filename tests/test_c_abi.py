@@ -45,6 +45,8 @@ def test_header_is_c99_and_the_python_mirror_has_the_same_layout(tmp_path):
     assert int(facts["sizeof_grx_plan_request"]) == C.sizeof(_lib.GrxPlanRequest)
     assert int(facts["sizeof_grx_beam_step_args"]) == C.sizeof(_lib.GrxBeamStepArgs)
     assert int(facts["sizeof_grx_beam_init_args"]) == C.sizeof(_lib.GrxBeamInitArgs)
+    assert int(facts["sizeof_grx_chunk"]) == C.sizeof(_lib.GrxChunk)
+    assert int(facts["noalloc_max_rows"]) == 65536
     assert int(facts["candidate_stride_242"]) == 256
     assert "null trie" in facts["null_trie_message"]
 
@@ -63,3 +65,5 @@ def test_plain_c_client_decodes_one_step_on_the_gpu(tmp_path):
     facts = _facts(run.stdout)
     assert float(facts["max_abs_logp_error"]) <= 1e-5  # fp32 tolerance of the log-probs
     assert int(facts["beam_step_groups_checked"]) == 3
+    assert int(facts["noalloc_rows_identical"]) == 12
+    assert float(facts["sliced_max_abs_logp_difference"]) <= 1e-5
