@@ -374,7 +374,15 @@ def main() -> None:
         local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    # GENREC_BENCH_FORCE_DIST=1: create the process group and issue every collective even with one rank
+    # (rehearses the RCCL code path of `--gpus N` on a one-GPU box)
+    dist_on = world > 1 or os.environ.get("GENREC_BENCH_FORCE_DIST", "0") not in ("", "0")
+    if dist_on and world == 1:
+        os.environ["GENREC_AMD_SINGLE_RANK_COLLECTIVES"] = "1"
+        os.environ.setdefault("MASTER_PORT", "29623")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
@@ -389,10 +397,10 @@ def main() -> None:
     roll = Rollout(args, wl, device)
 
     def barrier():
-        if world > 1:
+        if dist_on:
             dist.barrier()
 
-    if world > 1:
+    if dist_on:
         # set the communicator's all-gather path up outside the timed region even when the warm-up is
         # shorter than one rollout (the first collective of a process group connects its transports)
         from genrec_amd.advantage import gather_rows
@@ -425,7 +433,7 @@ def main() -> None:
     lib.grx_timing_enable(0)
     wl["proc"].check_errors()
 
-    if world > 1:
+    if dist_on:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -486,7 +494,7 @@ def main() -> None:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = time_cpu_baseline(args, wl)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -30,3 +30,21 @@ def test_two_rank_bench_line():
     assert abs(d["value"] - 2 * 10 / (d["ms_per_step"] * 10 / 1e3)) <= 1e-6 * d["value"]
     assert d["roofline"]["launches_timed"] >= 2 and d["roofline"]["achieved"] > 0
     assert "cpu_baseline" not in d  # rank 0 at N = 1 only
+
+
+@pytest.mark.gpu
+def test_bench_through_rccl_with_one_rank():
+    """`bench.py` with the process group created on backend "nccl" (RCCL) and every collective of the
+    multi-rank flow issued -- barriers, the asynchronous reward all-gather per rollout, the max-reduction of
+    the elapsed time -- with the one rank a one-GPU box can give it (GENREC_BENCH_FORCE_DIST=1)."""
+    env = dict(os.environ, GENREC_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29631")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "5", "--batch", "64",
+           "--no-cpu-baseline", "--no-processor-surface"]
+    run = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=280)
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-4000:]
+    lines = [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["roofline"]["launches_timed"] >= 2
