@@ -400,6 +400,13 @@ def main() -> None:
         if dist_on:
             dist.barrier()
 
+    if dist_on and backend == "nccl" and os.environ.get("GENREC_BENCH_NATIVE_RCCL", "0") not in ("", "0"):
+        # the exchange step through the library's own RCCL communicator (on the compute stream) instead of
+        # torch.distributed, which then only carries the communicator id
+        from genrec_amd import advantage
+        from genrec_amd.comm import RcclComm
+
+        advantage.use_native_comm(RcclComm.from_process_group(device))
     if dist_on:
         # set the communicator's all-gather path up outside the timed region even when the warm-up is
         # shorter than one rollout (the first collective of a process group connects its transports)

@@ -54,6 +54,10 @@ EXPORTED_SYMBOLS = (
     "grx_hit_ranks",
     "grx_group_advantage",
     "grx_group_normalize_tokenwise",
+    "grx_comm_unique_id",
+    "grx_comm_create",
+    "grx_comm_destroy",
+    "grx_comm_allgather",
 )
 
 
@@ -252,6 +256,14 @@ def _declare(lib: C.CDLL) -> None:
     lib.grx_hit_ranks.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp]
     lib.grx_group_advantage.restype = C.c_int
     lib.grx_group_advantage.argtypes = [vp, vp, i32, i32, i32, i32, f32, vp, vp, vp, vp, vp]
+    lib.grx_comm_unique_id.restype = C.c_int
+    lib.grx_comm_unique_id.argtypes = [vp]
+    lib.grx_comm_create.restype = C.c_int
+    lib.grx_comm_create.argtypes = [vp, i32, i32, C.POINTER(vp)]
+    lib.grx_comm_destroy.restype = C.c_int
+    lib.grx_comm_destroy.argtypes = [vp]
+    lib.grx_comm_allgather.restype = C.c_int
+    lib.grx_comm_allgather.argtypes = [vp, vp, vp, C.c_size_t, vp]
     lib.grx_group_normalize_tokenwise.restype = C.c_int
     lib.grx_group_normalize_tokenwise.argtypes = [vp, vp, i32, i32, i32, f32, vp, vp]
 

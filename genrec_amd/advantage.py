@@ -28,6 +28,8 @@ _SCALE = {"none": 0, "group": 1, "batch": 2}
 
 def gather_rows(t: torch.Tensor) -> torch.Tensor:
     """All-gather along dim 0 (``accelerate.utils.gather``); identity without a process group."""
+    if _native_comm is not None and t.is_cuda:
+        return _native_comm.allgather(t)
     if not (dist.is_available() and dist.is_initialized()):
         return t
     if dist.get_world_size() == 1 and not _single_rank_collectives():
@@ -147,6 +149,17 @@ class RolloutAdvantages:
         return tuple(self)[i]
 
 
+_native_comm = None
+
+
+def use_native_comm(comm) -> None:
+    """Route the exchange step's all-gather of device tensors through ``comm`` (a
+    ``genrec_amd.comm.RcclComm``): RCCL on the compute stream instead of ``torch.distributed``.
+    ``None`` switches back."""
+    global _native_comm
+    _native_comm = comm
+
+
 def _single_rank_collectives() -> bool:
     """GENREC_AMD_SINGLE_RANK_COLLECTIVES=1: issue the collective even in a process group of one rank
     (lets a one-GPU box run the RCCL code path itself; off by default, where one rank gathers nothing)."""
@@ -157,6 +170,8 @@ def _single_rank_collectives() -> bool:
 
 def _start_gather(t: torch.Tensor):
     """Begin ``gather_rows(t)`` without waiting: (work, output tensor, device to move it to or None)."""
+    if _native_comm is not None and t.is_cuda:
+        return None, _native_comm.allgather(t), None  # stream-ordered: nothing to wait for
     if not (dist.is_available() and dist.is_initialized()):
         return None, t, None
     if dist.get_world_size() == 1 and not _single_rank_collectives():

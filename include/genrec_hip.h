@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define GRX_ABI_VERSION 8
+#define GRX_ABI_VERSION 9
 
 #if defined(GRX_BUILDING)
 #define GRX_API __attribute__((visibility("default")))
@@ -503,6 +503,26 @@ GRX_API int grx_hit_ranks(const int32_t* beams, const int32_t* target, int32_t n
 GRX_API int grx_group_advantage(const float* rewards_per_func, const float* weights, int32_t R, int32_t n_funcs,
                         int32_t K, int32_t scale, float eps, float* rewards, float* advantages,
                         float* group_mean, float* group_std, void* stream);
+
+/*
+ * The exchange step of a rollout shard inside the library: the all-gather of the per-rank reward
+ * matrices that the reference issues through accelerate (`gather(rewards_per_func)`,
+ * fixed_hint_grpo_trainer.py:382; token_prefix_grpo_trainer.py:215,241-242,249,274), as an RCCL
+ * all-gather enqueued on the caller's stream -- reward kernel, gather and advantage kernel are then
+ * ordered by that one stream.  One process per GPU: rank 0 draws an id with grx_comm_unique_id
+ * (GRX_COMM_ID_BYTES opaque bytes), hands it to the other ranks by any means (a file, a
+ * torch.distributed store), and every rank calls grx_comm_create with the device it will use
+ * current (collective: returns when all n_ranks have called).  grx_comm_allgather places rank i's
+ * bytes_per_rank bytes at recv + i * bytes_per_rank on every rank; device buffers.  RCCL is bound
+ * at run time (librccl.so, the copy already in the process if there is one); without it these
+ * calls return GRX_E_UNSUPPORTED and the rest of the library is unaffected.
+ */
+#define GRX_COMM_ID_BYTES 128
+typedef struct grx_comm grx_comm;
+GRX_API int grx_comm_unique_id(void* id_out);
+GRX_API int grx_comm_create(const void* id, int32_t n_ranks, int32_t rank, grx_comm** out);
+GRX_API int grx_comm_destroy(grx_comm* comm);
+GRX_API int grx_comm_allgather(grx_comm* comm, const void* send, void* recv, size_t bytes_per_rank, void* stream);
 
 /*
  * Token-wise masked group normalisation

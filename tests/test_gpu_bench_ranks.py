@@ -42,9 +42,11 @@ def test_bench_through_rccl_with_one_rank():
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "5", "--batch", "64",
            "--no-cpu-baseline", "--no-processor-surface"]
-    run = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=280)
-    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-4000:]
-    lines = [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1
-    d = json.loads(lines[0])
-    assert d["n_gpus"] == 1 and d["value"] > 0 and d["roofline"]["launches_timed"] >= 2
+    for native in ("0", "1"):  # the gather through torch.distributed, then through the library's own communicator
+        run = subprocess.run(cmd, env=dict(env, GENREC_BENCH_NATIVE_RCCL=native), cwd=ROOT, capture_output=True,
+                             text=True, timeout=280)
+        assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-4000:]
+        lines = [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == 1 and d["value"] > 0 and d["roofline"]["launches_timed"] >= 2

@@ -33,3 +33,13 @@ def test_the_rccl_code_path_runs_with_one_rank():
     run = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=200)
     assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-4000:]
     assert "rccl single rank ok" in run.stdout
+
+
+@pytest.mark.gpu
+def test_the_librarys_own_rccl_communicator_with_one_rank():
+    """grx_comm_unique_id / grx_comm_create / grx_comm_allgather (RCCL bound at run time, the collective
+    enqueued on the compute stream) and the exchange step routed through them."""
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "workers", "native_rccl.py")], cwd=ROOT,
+                         capture_output=True, text=True, timeout=200)
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-4000:]
+    assert "native rccl ok" in run.stdout
