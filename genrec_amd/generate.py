@@ -99,6 +99,28 @@ class SlicedLMHead:
         call.finish()
 
 
+def reorder_generated_suffix(cache, beam_idx: torch.Tensor, prompt_len: int) -> None:
+    """KV-cache re-ordering for beams that share their prompt.
+
+    ``generate()`` re-orders the whole cache every step (``cache.reorder_cache``: an ``index_select`` over
+    [rows, heads, T, D] per layer, keys and values).  The K beams of a group are copies of one prompt and a
+    beam's parent always lies in its own group, so positions below ``prompt_len`` are identical across the
+    rows being exchanged: only the generated suffix has to move -- a few tokens instead of the whole prompt.
+    Caches whose layers are not plain [rows, heads, T, D] key / value tensors take the general route."""
+    layers = getattr(cache, "layers", None)
+    if not layers or not all(
+            getattr(l, "keys", None) is not None and torch.is_tensor(l.keys) and l.keys.dim() == 4
+            and not getattr(l, "is_sliding", False) for l in layers):
+        cache.reorder_cache(beam_idx)
+        return
+    for layer in layers:
+        if layer.keys.shape[2] <= prompt_len:
+            continue  # nothing generated yet: every row of a group holds the same cache
+        idx = beam_idx.to(layer.keys.device)
+        layer.keys[:, :, prompt_len:, :] = layer.keys[:, :, prompt_len:, :].index_select(0, idx)
+        layer.values[:, :, prompt_len:, :] = layer.values[:, :, prompt_len:, :].index_select(0, idx)
+
+
 @dataclass
 class ConstrainedBeamOutput:
     sequences: torch.Tensor         # [B * num_return_sequences, prompt_len + generated]
@@ -216,7 +238,7 @@ def constrained_generate(
         if step >= max_new_tokens:
             break
         # ---- model side of the next step: re-order the cache, feed the tokens just chosen
-        cache.reorder_cache(res.next_parent.long())
+        reorder_generated_suffix(cache, res.next_parent.long(), T)
         new_tokens = state.running_sequences.view(B * K, -1)[:, state.cur_len - 1 : state.cur_len]
         mask = torch.cat([mask, torch.ones((B * K, 1), dtype=mask.dtype, device=dev)], dim=1)
         logits, cache = forward(input_ids=new_tokens, attention_mask=mask, position_ids=next_pos,
