@@ -49,7 +49,7 @@ def _random_case(rng):
             rows[r, -1] = eos                         # finished row
         # else: leave random tokens (leaves the trie / no prefix at all)
     count = int(rng.integers(0, levels + 2)) if rng.random() < 0.3 else step
-    return dict(V=V, prefix=prefix, eos=eos, seqs=seqs, K=K, rows=rows.astype(np.int64), count=count,
+    return dict(V=V, prefix=prefix, eos=eos, seqs=seqs, K=K, rows=rows.astype(np.int64), count=count, step=step,
                 use_prefix_ids=bool(rng.random() < 0.6), dtype=[torch.float32, torch.bfloat16][int(rng.integers(0, 2))])
 
 
@@ -106,6 +106,112 @@ def test_random_tries_rows_and_counters(block):
             assert torch.equal(cand.tokens.cpu()[valid].long(), cols)
             assert float((cand.logp.cpu()[valid] - want[fin]).abs().max()) <= TOL
     assert outcomes["ok"] >= 10 and outcomes["AssertionError"] + outcomes["ValueError"] >= 5, outcomes
+
+
+@pytest.mark.parametrize("block", range(4))
+def test_random_slicings_and_row_cuts_agree_with_whole_rows(block):
+    """The same random tries, rows and counters through the sliced step (random slice borders, fed in
+    random order) and through the row cut (`keep_top` with random running scores): whatever the oracle
+    accepts must come out of the slices as it does from whole rows -- tokens and counts bit for bit,
+    log-probs within 1e-5 of the oracle -- and the cut rows must hold exactly the best entries of the
+    whole rows by (fp32(logp + running score) descending, token ascending)."""
+    from oracle.processors import (DictTrie, RefConstrainedLogitsProcessor,
+                                   RefFixedHintConstrainedLogitsProcessor)
+
+    from genrec_amd.fixed_hint_logit_processor import FixedHintConstrainedLogitsProcessor
+    from genrec_amd.logit_processor import Candidates, ConstrainedLogitsProcessor
+    from genrec_amd.trie import FlatTrie, create_prefix_allowed_tokens_fn
+
+    dev = _dev()
+    rng = np.random.default_rng(5000 + block)
+    n_ok = n_cut = 0
+    for _ in range(25):
+        c = _random_case(rng)
+        V = c["V"]
+        if V >= 200 and rng.random() < 0.6:
+            # wide nodes where the rows stand (up to twelve parents at the rows' depth), so rows have entries to shed
+            tail, n_pre, d = c["seqs"][0][-1:], len(c["prefix"]), c["step"]
+            parents = sorted({tuple(q[n_pre : n_pre + d]) for q in c["seqs"] if len(q) - n_pre - 1 >= d})[:12]
+            have = {tuple(q) for q in c["seqs"]}
+            for par in parents:
+                wide = rng.choice(np.arange(20, V), size=int(rng.integers(80, min(V - 20, 500))), replace=False)
+                for t in wide:
+                    q = c["prefix"] + list(par) + [int(t)] + tail
+                    if tuple(q) not in have:
+                        have.add(tuple(q))
+                        c["seqs"].append(q)
+        trie = FlatTrie(c["seqs"])
+        fn = create_prefix_allowed_tokens_fn(trie, c["prefix"])
+        get = DictTrie(c["seqs"]).get
+        ids = torch.from_numpy(c["rows"])
+        scores = (torch.randn(ids.shape[0], V, generator=torch.Generator().manual_seed(int(rng.integers(1 << 30))))
+                  * 4).to(c["dtype"])
+        pidx, K, eos = len(c["prefix"]), c["K"], c["eos"]
+        pids = c["prefix"] if c["use_prefix_ids"] else None
+        n_cuts = int(rng.integers(0, 5))
+        borders = sorted({0, V, *rng.integers(1, V, size=n_cuts).tolist()})
+        bounds = list(zip(borders[:-1], borders[1:]))
+        order = rng.permutation(len(bounds)).tolist()
+        for kind in ("count", "fixed"):
+            def make():
+                if kind == "count":
+                    p = ConstrainedLogitsProcessor(fn, K, pidx, pids, eos, sync_errors=True)
+                    p.count = c["count"]
+                    return p
+                return FixedHintConstrainedLogitsProcessor(fn, K, pidx, c["prefix"], eos, sync_errors=True)
+            if kind == "count":
+                ref = RefConstrainedLogitsProcessor(get, K, pidx, pids, eos)
+                ref.count = c["count"]
+            else:
+                ref = RefFixedHintConstrainedLogitsProcessor(get, K, pidx, c["prefix"], eos)
+            try:
+                want = ref(ids, scores.float())
+            except (AssertionError, ValueError):
+                continue  # the error conventions of the sliced step have a test of their own
+            n_ok += 1
+            fin = torch.isfinite(want)
+            whole = make().candidates(ids.to(dev), scores.to(dev))
+            # ---- the sliced step
+            sliced = make()
+            cand = Candidates(ids.shape[0], max(trie.max_fanout, 1), dev)
+            cand.buf.fill_(-7)
+            step = sliced.chunked_step(ids.to(dev), cand, V, bounds, scores.dtype)
+            dscores = scores.to(dev)
+            for i in order:
+                a, b = bounds[i]
+                step.feed(a, dscores[:, a:b])
+            got = step.finish()
+            sliced.check_errors()
+            tag = (kind, bounds, order, c["prefix"], c["count"])
+            assert torch.equal(got.count.cpu().long(), fin.sum(dim=1)), tag
+            valid = torch.arange(got.cmax)[None, :] < got.count.cpu()[:, None]
+            assert torch.equal(got.tokens.cpu()[valid].long(), torch.nonzero(fin)[:, 1]), tag
+            if bool(valid.any()):
+                assert float((got.logp.cpu()[valid] - want[fin]).abs().max()) <= TOL, tag
+            if kind == "count":
+                assert sliced.count == ref.count
+            # ---- the row cut
+            keep = int(rng.integers(1, 9))
+            if trie.max_fanout > 1024:
+                continue
+            bias = torch.from_numpy((rng.standard_normal(ids.shape[0]) * 2).astype(np.float32))
+            cut = Candidates(ids.shape[0], max(trie.max_fanout, 1), dev)
+            make().candidates_into(ids.to(dev), dscores, cut, keep_top=keep, row_bias=bias.to(dev))
+            wc, wt, wl = whole.count.cpu().numpy(), whole.tokens.cpu().numpy(), whole.logp.cpu().numpy()
+            gc, gt, gl = cut.count.cpu().numpy(), cut.tokens.cpu().numpy(), cut.logp.cpu().numpy()
+            for r in range(ids.shape[0]):
+                n = int(wc[r])
+                t, v = wt[r, :n], wl[r, :n]
+                if n > keep + 64:
+                    n_cut += 1
+                    ssum = (v + np.float32(bias[r].item())).astype(np.float32)
+                    sel = np.lexsort((t, -ssum.astype(np.float64)))[:keep]
+                    t, v = t[sel], v[sel]
+                assert gc[r] == len(t), (tag, r)
+                g, w = np.argsort(gt[r, : gc[r]], kind="stable"), np.argsort(t, kind="stable")
+                assert np.array_equal(gt[r, : gc[r]][g], t[w]), (tag, r)
+                assert np.array_equal(gl[r, : gc[r]][g].view(np.int32), v[w].view(np.int32)), (tag, r)
+    assert n_ok >= 10 and n_cut >= 1, (n_ok, n_cut)
 
 
 LIVE = -1.0e8  # scores above this belong to real hypotheses; placeholder beams sit near -1e9
