@@ -154,9 +154,10 @@ class Rollout:
             self.exchange = None
 
 
-def time_cpu_baseline(args, wl):
+def time_cpu_baseline(args, wl, cores=None):
     """The oracle (CPU restatement of the reference processor + HF beam step) on the workload's own
-    row count: one generation (`levels` steps over all batch x beams rows), timed step by step."""
+    row count: one generation (`levels` steps over all batch x beams rows), timed step by step, with
+    `cores` torch threads (default: the box's CPU share for one GPU, 16 cores)."""
     import torch
 
     from oracle.beam import RefBeamSearch
@@ -170,7 +171,7 @@ def time_cpu_baseline(args, wl):
     prompts = wl["prompts"][:groups].cpu().repeat_interleave(K, dim=0)
     V, levels = wl["V"], wl["levels"]
     # the box's CPU share for one GPU is 16 cores
-    cores = min(16, os.cpu_count() or 1)
+    cores = min(cores or 16, os.cpu_count() or 1)
     torch.set_num_threads(cores)
     t_total, n_steps = 0.0, 0
     while n_steps < levels or (t_total < args.cpu_seconds and groups < args.batch):
@@ -500,6 +501,9 @@ def main() -> None:
             out["processor_surface"] = time_processor_surface(args, wl, device)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = time_cpu_baseline(args, wl)
+            if out["cpu_baseline"]["cores"] > 8:  # the same sample on 8 threads, beside the whole CPU share
+                at8 = time_cpu_baseline(args, wl, cores=8)
+                out["cpu_baseline"]["at_8_cores"] = {"value": at8["value"], "sample": at8["sample"]}
         print(json.dumps(out), flush=True)
     if dist_on:
         dist.barrier()

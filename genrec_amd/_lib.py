@@ -43,6 +43,7 @@ EXPORTED_SYMBOLS = (
     "grx_chunk_parts",
     "grx_constrained_partial",
     "grx_constrained_finish",
+    "grx_constrained_finish_penalised",
     "grx_timing_enable",
     "grx_timing_read",
     "grx_read_probe",
@@ -99,6 +100,8 @@ class GrxChunk(C.Structure):
         ("n_slots", C.c_int32),
         ("parts", C.c_int32),
         ("first", C.c_int32),
+        ("pen_logits", C.c_void_p),
+        ("pen_stride", C.c_int64),
     ]
 
 
@@ -233,6 +236,10 @@ def _declare(lib: C.CDLL) -> None:
     ]
     lib.grx_constrained_finish.restype = C.c_int
     lib.grx_constrained_finish.argtypes = [i32, i32, vp, vp, i64, i32, vp, C.c_size_t, vp]
+    lib.grx_constrained_finish_penalised.restype = C.c_int
+    lib.grx_constrained_finish_penalised.argtypes = [
+        C.POINTER(GrxRows), C.POINTER(GrxConstraint), i32, i32, vp, vp, i64, vp, i64, i32, vp, C.c_size_t, vp,
+    ]
     lib.grx_candidate_stride.restype = i64
     lib.grx_candidate_stride.argtypes = [i32]
     lib.grx_timing_enable.restype = C.c_int

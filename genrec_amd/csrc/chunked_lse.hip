@@ -50,6 +50,10 @@ struct ChunkArgs {
     grx_cand* cand;
     int64_t cand_stride;
     int cmax;
+    // repetition penalty: raw logits of the tokens ids[r, pen_from:T) that lie inside this launch's columns
+    float* pen_logits;    // [R, pen_stride], entry t belongs to ids[r, pen_from + t]; null: no penalty
+    int64_t pen_stride;
+    int pen_from;
 };
 
 // (max, sum of exp(x - max)) of everything the lanes of one wave have accumulated.
@@ -170,6 +174,16 @@ __global__ __launch_bounds__(CH_THREADS) void chunk_lse_kernel(ChunkArgs a) {
             }
         }
     }
+    // ... and of the tokens the repetition penalty will touch (the row's own ids)
+    if (a.pen_logits != nullptr) {
+        const int64_t* __restrict__ ids_row = a.ids + (int64_t)r * a.ids_stride;
+        float* __restrict__ prow = a.pen_logits + (int64_t)r * a.pen_stride;
+        const int64_t t_lo = (int64_t)a.v_begin + col_lo, t_hi = (int64_t)a.v_begin + col_hi;
+        for (int t = a.pen_from + lane; t < a.T; t += GRX_WAVE) {
+            const int64_t tk = ids_row[t];
+            if (tk >= t_lo && tk < t_hi) prow[t - a.pen_from] = E::to_float(row[tk - a.v_begin]);
+        }
+    }
 }
 
 // One wave per row: merge the row's partial pairs in slot order, then rewrite the candidate row in
@@ -207,6 +221,119 @@ __global__ __launch_bounds__(CH_THREADS) void chunk_finish_kernel(const grx_row_
             const grx_cand raw = crow[e];
             v.x = raw.x;
             v.y = __float_as_int((__int_as_float(raw.y) - M) - log_s);
+        }
+        cand_store(crow + e, v);
+    }
+}
+
+// The same with transformers' repetition penalty applied to the log-softmax before the mask, as
+// the whole-row kernel does it: y_v <- y_v * p (y_v < 0) or y_v / p for every distinct token v of
+// ids[r, pen_from:T) inside the vocabulary, the row normalised again.  Only those tokens move, so the
+// second log-sum-exp follows from the first: sum_v exp(y'_v) = (S - sum_U exp(x_v - M)) / S + sum_U exp(y'_v).
+// One workgroup per row; the distinct tokens are an open-addressing set in LDS, which the candidate
+// pass then consults.
+struct FinishPenArgs {
+    const grx_row_plan* plan;
+    const float2* partials;
+    int n_slots;
+    int R;
+    grx_cand* cand;
+    int64_t cand_stride;
+    int cmax;
+    const int64_t* ids;
+    int64_t ids_stride;
+    int T;
+    int pen_from;
+    int v_total;
+    float penalty;
+    const float* pen_logits;
+    int64_t pen_stride;
+};
+
+__global__ __launch_bounds__(CH_THREADS) void chunk_finish_pen_kernel(FinishPenArgs a) {
+    __shared__ int s_pen[PEN_SLOTS];
+    __shared__ float s_red[2][CH_WAVES];
+    const int tid = threadIdx.x;
+    const int lane = tid & (GRX_WAVE - 1);
+    const int r = blockIdx.x;
+    const grx_row_plan pl = a.plan[r];
+    int c_n = pl.n;
+    if (c_n > a.cmax || c_n < 0) c_n = 0;
+    grx_cand* __restrict__ crow = a.cand + (int64_t)r * a.cand_stride;
+    const int n_line = ((c_n + 1 + 15) / 16) * 16;
+    // every wave merges the row's pairs for itself (same order in each: identical results, no exchange)
+    const float2* __restrict__ prow = a.partials + (int64_t)r * a.n_slots;
+    float m = -INFINITY;
+    for (int p = lane; p < a.n_slots; p += GRX_WAVE) m = fmaxf(m, prow[p].x);
+    const float M = wave_max(m);
+    const float Mref = (M == -INFINITY) ? 0.f : M;
+    float s = 0.f;
+    for (int p = lane; p < a.n_slots; p += GRX_WAVE) {
+        const float2 v = prow[p];
+        s += v.y * fast_exp2((v.x - Mref) * kLog2e);
+    }
+    const float S = wave_sum(s);
+    const float log_s = logf(S);
+    auto penalised = [&](float y) { return y < 0.f ? y * a.penalty : y / a.penalty; };
+
+    for (int i = tid; i < PEN_SLOTS; i += CH_THREADS) s_pen[i] = -1;
+    __syncthreads();
+    const int64_t* __restrict__ ids_row = a.ids + (int64_t)r * a.ids_stride;
+    const float* __restrict__ pen_row = a.pen_logits + (int64_t)r * a.pen_stride;
+    float sub = 0.f, add = 0.f;
+    for (int t = a.pen_from + tid; t < a.T; t += CH_THREADS) {
+        const int64_t tk = ids_row[t];
+        if (tk < 0 || tk >= (int64_t)a.v_total) continue;
+        const int tokv = (int)tk;
+        uint32_t h = ((uint32_t)tokv * 0x9E3779B1u) >> (32 - PEN_SLOT_BITS);
+        bool first = false;
+        for (;;) {
+            const int old = atomicCAS(&s_pen[h], -1, tokv);
+            if (old == -1) { first = true; break; }
+            if (old == tokv) break;
+            h = (h + 1) & (PEN_SLOTS - 1);
+        }
+        if (first) {
+            const float xm = pen_row[t - a.pen_from] - M;
+            sub += fast_exp2(xm * kLog2e);
+            add += fast_exp2(penalised(xm - log_s) * kLog2e);
+        }
+    }
+    sub = wave_sum(sub);
+    add = wave_sum(add);
+    if (lane == 0) {
+        s_red[0][tid / GRX_WAVE] = sub;
+        s_red[1][tid / GRX_WAVE] = add;
+    }
+    __syncthreads();  // also publishes the finished token set
+    sub = 0.f;
+    add = 0.f;
+#pragma unroll
+    for (int w = 0; w < CH_WAVES; ++w) {
+        sub += s_red[0][w];
+        add += s_red[1][w];
+    }
+    const float lse2 = logf(fmaxf(S - sub, 0.f) / S + add);
+    auto in_pen_set = [&](int tokv) {
+        uint32_t h = ((uint32_t)tokv * 0x9E3779B1u) >> (32 - PEN_SLOT_BITS);
+        for (;;) {
+            const int cur = s_pen[h];
+            if (cur == tokv) return true;
+            if (cur < 0) return false;
+            h = (h + 1) & (PEN_SLOTS - 1);
+        }
+    };
+    for (int e = tid; e < n_line; e += CH_THREADS) {
+        grx_cand v = {0, 0};
+        if (e == 0) {
+            v.x = c_n;
+            v.y = __float_as_int(M + log_s + lse2);
+        } else if (e - 1 < c_n) {
+            const grx_cand raw = crow[e];
+            float y = (__int_as_float(raw.y) - M) - log_s;
+            if (in_pen_set(raw.x)) y = penalised(y);
+            v.x = raw.x;
+            v.y = __float_as_int(y - lse2);
         }
         cand_store(crow + e, v);
     }
@@ -265,9 +392,21 @@ extern "C" int grx_constrained_partial(const grx_trie* trie, grx_state* state, c
                 GRX_E_INVALID, "%s: slots [%d, %d) outside the %d slots per row (at most %d)", who, chunk->slot,
                 chunk->slot + chunk->parts, chunk->n_slots, GRX_MAX_PARTIAL_SLOTS);
     const bool penalise = con->repetition_penalty != 0.f && con->repetition_penalty != 1.f;
-    GRX_REQUIRE(!penalise && con->assume_normalized == 0, GRX_E_UNSUPPORTED,
-                "%s: the repetition penalty and assume_normalized need whole rows (use grx_constrained_candidates)",
+    GRX_REQUIRE(con->assume_normalized == 0, GRX_E_UNSUPPORTED,
+                "%s: assume_normalized needs whole rows (use grx_constrained_candidates)", who);
+    GRX_REQUIRE(con->keep_top == 0, GRX_E_UNSUPPORTED, "%s: keep_top needs whole rows (use grx_constrained_candidates)",
                 who);
+    if (penalise) {
+        GRX_REQUIRE(con->repetition_penalty > 0.f, GRX_E_INVALID, "%s: repetition_penalty must be positive", who);
+        GRX_REQUIRE(con->penalty_skip >= 0, GRX_E_INVALID, "%s: penalty_skip must be >= 0", who);
+        GRX_REQUIRE(rows->T - con->penalty_skip <= GRX_MAX_PENALTY_TOKENS, GRX_E_UNSUPPORTED,
+                    "%s: repetition penalty over more than %d tokens per row", who, GRX_MAX_PENALTY_TOKENS);
+        GRX_REQUIRE(rows->R == 0 || rows->T <= con->penalty_skip ||
+                        (chunk->pen_logits != nullptr && ((uintptr_t)chunk->pen_logits & 3u) == 0 &&
+                         chunk->pen_stride >= rows->T - con->penalty_skip),
+                    GRX_E_INVALID, "%s: the repetition penalty needs grx_chunk.pen_logits [R, >= %d] fp32", who,
+                    rows->T - con->penalty_skip);
+    }
     GRX_REQUIRE(chunk->first == 1 || rows->planned == 0, GRX_E_INVALID,
                 "%s: planned = 1 is only meaningful on the call that opens the step", who);
     GRX_REQUIRE(cmax >= 1, GRX_E_INVALID, "%s: cmax must be >= 1", who);
@@ -312,6 +451,11 @@ extern "C" int grx_constrained_partial(const grx_trie* trie, grx_state* state, c
     a.cand = cand;
     a.cand_stride = cand_stride;
     a.cmax = cmax;
+    if (penalise && rows->T > con->penalty_skip) {
+        a.pen_logits = chunk->pen_logits;
+        a.pen_stride = chunk->pen_stride;
+        a.pen_from = con->penalty_skip;
+    }
     const int lo = chunk->v_begin, hi = chunk->v_begin + rows->V;
     a.gather = (trie_token_in_range(trie, lo, hi) || (con->eos_token_id >= lo && con->eos_token_id < hi)) ? 1 : 0;
     const size_t es = ch_dtype_size(rows->dtype);
@@ -344,6 +488,59 @@ extern "C" int grx_constrained_finish(int32_t R, int32_t n_slots, const float* p
     hipLaunchKernelGGL(chunk_finish_kernel, dim3((unsigned)((R + CH_WAVES - 1) / CH_WAVES)), dim3(CH_THREADS), 0,
                        (hipStream_t)stream, plan, reinterpret_cast<const float2*>(partials), n_slots, R, cand,
                        cand_stride, cmax);
+    GRX_CHECK_HIP(hipGetLastError());
+    return GRX_OK;
+}
+
+extern "C" int grx_constrained_finish_penalised(const grx_rows* rows, const grx_constraint* con, int32_t v_total,
+                                                int32_t n_slots, const float* partials, const float* pen_logits,
+                                                int64_t pen_stride, grx_cand* cand, int64_t cand_stride,
+                                                int32_t cmax, const void* workspace, size_t workspace_bytes,
+                                                void* stream) {
+    const char* who = "grx_constrained_finish_penalised";
+    GRX_REQUIRE(rows != nullptr && con != nullptr, GRX_E_INVALID, "%s: null rows/constraint", who);
+    const bool penalise = con->repetition_penalty != 0.f && con->repetition_penalty != 1.f;
+    if (!penalise || rows->T <= con->penalty_skip || rows->R <= 0)  // nothing to penalise
+        return grx_constrained_finish(rows->R, n_slots, partials, cand, cand_stride, cmax, workspace, workspace_bytes,
+                                      stream);
+    const int32_t R = rows->R;
+    GRX_REQUIRE(con->repetition_penalty > 0.f && con->penalty_skip >= 0, GRX_E_INVALID,
+                "%s: repetition_penalty must be positive, penalty_skip >= 0", who);
+    GRX_REQUIRE(rows->T - con->penalty_skip <= GRX_MAX_PENALTY_TOKENS, GRX_E_UNSUPPORTED,
+                "%s: repetition penalty over more than %d tokens per row", who, GRX_MAX_PENALTY_TOKENS);
+    GRX_REQUIRE(rows->input_ids != nullptr && rows->ids_stride >= rows->T, GRX_E_INVALID, "%s: bad input_ids", who);
+    GRX_REQUIRE(v_total >= 1, GRX_E_INVALID, "%s: v_total must be >= 1", who);
+    GRX_REQUIRE(pen_logits != nullptr && ((uintptr_t)pen_logits & 3u) == 0 && pen_stride >= rows->T - con->penalty_skip,
+                GRX_E_INVALID, "%s: needs the pen_logits [R, >= %d] of the partial calls", who,
+                rows->T - con->penalty_skip);
+    GRX_REQUIRE(n_slots >= 1 && n_slots <= GRX_MAX_PARTIAL_SLOTS, GRX_E_INVALID, "%s: n_slots must be in [1, %d]", who,
+                GRX_MAX_PARTIAL_SLOTS);
+    GRX_REQUIRE(partials != nullptr && ((uintptr_t)partials & 7u) == 0, GRX_E_INVALID,
+                "%s: partials must be an 8-byte aligned device buffer", who);
+    GRX_REQUIRE(cmax >= 1 && cand_stride >= grx_candidate_stride(cmax) && cand_stride % 16 == 0, GRX_E_INVALID,
+                "%s: bad cmax / cand_stride", who);
+    GRX_REQUIRE(cand != nullptr && ((uintptr_t)cand & 127u) == 0, GRX_E_INVALID,
+                "%s: cand must be a 128-byte aligned device buffer", who);
+    GRX_REQUIRE(workspace != nullptr && ((uintptr_t)workspace & 15u) == 0 && workspace_bytes >= grx_workspace_bytes(R),
+                GRX_E_WORKSPACE, "%s: needs the workspace of the partial calls (%zu bytes)", who, grx_workspace_bytes(R));
+    FinishPenArgs a;
+    memset(&a, 0, sizeof(a));
+    a.plan = reinterpret_cast<const grx_row_plan*>(reinterpret_cast<const char*>(workspace) + GRX_WS_PLAN_OFFSET);
+    a.partials = reinterpret_cast<const float2*>(partials);
+    a.n_slots = n_slots;
+    a.R = R;
+    a.cand = cand;
+    a.cand_stride = cand_stride;
+    a.cmax = cmax;
+    a.ids = rows->input_ids;
+    a.ids_stride = rows->ids_stride;
+    a.T = rows->T;
+    a.pen_from = con->penalty_skip;
+    a.v_total = v_total;
+    a.penalty = con->repetition_penalty;
+    a.pen_logits = pen_logits;
+    a.pen_stride = pen_stride;
+    hipLaunchKernelGGL(chunk_finish_pen_kernel, dim3((unsigned)R), dim3(CH_THREADS), 0, (hipStream_t)stream, a);
     GRX_CHECK_HIP(hipGetLastError());
     return GRX_OK;
 }

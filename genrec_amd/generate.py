@@ -154,7 +154,7 @@ def constrained_generate(
     steps (a trie of L levels always takes L + 1) and avoids the per-step host check of HF's loop
     condition.  ``share_prefill=False`` prefills all K copies like ``generate()`` does.
     ``lm_head_slice`` (columns): run the LM head slice by slice through :class:`SlicedLMHead` instead
-    of materialising [rows, vocab] logits; not with a repetition penalty on the processor.
+    of materialising [rows, vocab] logits (the fused repetition penalty works there too).
     """
     B, T = input_ids.shape
     K = int(num_beams)

@@ -101,9 +101,8 @@ class ChunkedStep:
 
     def __init__(self, proc, input_ids, cand: Candidates, v_total: int, bounds, dtype, one_row_per_group: bool,
                  parts: Optional[int] = None):
-        if proc.repetition_penalty != 1.0 or proc.assume_normalized:
-            raise _lib.GenrecHipError("the chunked step supports neither the fused repetition penalty nor "
-                                      "assume_normalized (both need whole rows)")
+        if proc.assume_normalized:
+            raise _lib.GenrecHipError("the chunked step does not support assume_normalized (it needs whole rows)")
         bounds = [(int(a), int(b)) for a, b in bounds]
         covered = sorted(bounds)
         if not covered or covered[0][0] != 0 or covered[-1][1] != int(v_total) or any(
@@ -134,11 +133,21 @@ class ChunkedStep:
         self.n_slots = n
         self.index = proc._device_index(input_ids)
         self.partials = proc._partials(self.index, self.R * n * 2)
+        # fused repetition penalty: the slices leave the raw logits of every row's own tokens here
+        self.pen_width = max(input_ids.shape[1] - proc.prompt_ignore_length, 0) if proc.repetition_penalty != 1.0 else 0
+        self.pen_logits = proc._pen_logits(self.index, self.R * self.pen_width) if self.pen_width else None
         self.fed = 0
         with torch.cuda.device(self.index):
             self.state = proc._state(self.index)
             self.ws = proc._workspace(self.index, self.R)
         self.con = proc._constraint()
+
+    def _rows(self) -> "_lib.GrxRows":
+        rows = _lib.GrxRows()
+        rows.input_ids = self.ids.data_ptr()
+        rows.ids_stride = self.ids.stride(0) if self.R > 1 else max(self.ids.shape[1], 1)
+        rows.R, rows.T = self.R, self.ids.shape[1]
+        return rows
 
     def feed(self, v_begin: int, scores: torch.Tensor) -> None:
         """``scores`` [rows, v_end - v_begin]: the logits of tokens ``v_begin .. v_end - 1``."""
@@ -149,10 +158,7 @@ class ChunkedStep:
             raise ValueError(f"slice at {v_begin} must be [{self.R}, {v_end - v_begin}] {self.dtype} on {self.ids.device}")
         if scores.stride(1) != 1:
             scores = scores.contiguous()
-        rows = _lib.GrxRows()
-        rows.input_ids = self.ids.data_ptr()
-        rows.ids_stride = self.ids.stride(0) if self.R > 1 else max(self.ids.shape[1], 1)
-        rows.R, rows.T = self.R, self.ids.shape[1]
+        rows = self._rows()
         rows.scores = scores.data_ptr()
         rows.scores_stride = scores.stride(0) if self.R > 1 else scores.shape[1]
         rows.V = scores.shape[1]
@@ -161,6 +167,8 @@ class ChunkedStep:
         chunk.v_begin, chunk.v_total = int(v_begin), self.v_total
         chunk.slot, chunk.n_slots, chunk.parts = slot, self.n_slots, parts
         chunk.first = 1 if self.fed == 0 else 0
+        if self.pen_logits is not None:
+            chunk.pen_logits, chunk.pen_stride = self.pen_logits.data_ptr(), self.pen_width
         if chunk.first:
             proc._take_planned(rows, self.ids)
         with torch.cuda.device(self.index):
@@ -178,12 +186,22 @@ class ChunkedStep:
         if self.fed != len(self.slots):
             raise RuntimeError(f"{self.fed} of {len(self.slots)} column slices were fed")
         with torch.cuda.device(self.index):
-            _lib.check(
-                _lib.lib().grx_constrained_finish(
-                    self.R, self.n_slots, self.partials.data_ptr(), self.cand.buf.data_ptr(), self.cand.stride,
-                    self.cand.cmax, self.ws.data_ptr(), self.ws.numel(), _lib.current_stream_ptr(self.ids.device),
+            if self.pen_logits is not None:
+                rows = self._rows()
+                _lib.check(
+                    _lib.lib().grx_constrained_finish_penalised(
+                        C.byref(rows), C.byref(self.con), self.v_total, self.n_slots, self.partials.data_ptr(),
+                        self.pen_logits.data_ptr(), self.pen_width, self.cand.buf.data_ptr(), self.cand.stride,
+                        self.cand.cmax, self.ws.data_ptr(), self.ws.numel(), _lib.current_stream_ptr(self.ids.device),
+                    )
                 )
-            )
+            else:
+                _lib.check(
+                    _lib.lib().grx_constrained_finish(
+                        self.R, self.n_slots, self.partials.data_ptr(), self.cand.buf.data_ptr(), self.cand.stride,
+                        self.cand.cmax, self.ws.data_ptr(), self.ws.numel(), _lib.current_stream_ptr(self.ids.device),
+                    )
+                )
         if self.proc.sync_errors:
             self.proc.check_errors()
         return self.cand
@@ -239,6 +257,7 @@ class _TrieConstrainedBase(LogitsProcessor):
         self._states: dict[int, _DeviceState] = {}
         self._workspaces: dict[int, torch.Tensor] = {}
         self._partial_bufs: dict[int, torch.Tensor] = {}
+        self._pen_bufs: dict[int, torch.Tensor] = {}
         self._active: Optional[int] = None  # device index of the last call
         self._call_seq = 0                  # processor calls made so far (host side)
         self._planned: Optional[tuple] = None  # rows whose plans a beam kernel has already written
@@ -278,6 +297,13 @@ class _TrieConstrainedBase(LogitsProcessor):
         if buf is None or buf.numel() < n_floats:
             buf = torch.empty(n_floats, dtype=torch.float32, device=torch.device("cuda", index))
             self._partial_bufs[index] = buf
+        return buf
+
+    def _pen_logits(self, index: int, n_floats: int) -> torch.Tensor:
+        buf = self._pen_bufs.get(index)
+        if buf is None or buf.numel() < n_floats:
+            buf = torch.empty(n_floats, dtype=torch.float32, device=torch.device("cuda", index))
+            self._pen_bufs[index] = buf
         return buf
 
     # -- planning ahead (fused loop) -----------------------------------------------------

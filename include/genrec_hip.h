@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define GRX_ABI_VERSION 9
+#define GRX_ABI_VERSION 10
 
 #if defined(GRX_BUILDING)
 #define GRX_API __attribute__((visibility("default")))
@@ -257,7 +257,16 @@ GRX_API int grx_constrained_candidates_noalloc(const grx_trie* trie, grx_state* 
  * opens the processor call: `count` advances, rows are resolved, row errors are
  * reported -- must be ordered before the others and grx_constrained_finish after
  * all of them (one stream, or events).  partials is device fp32 [R, n_slots, 2].
- * Not available with the fused repetition penalty or assume_normalized.
+ * Not available with assume_normalized or keep_top (both need whole rows).
+ *
+ * With the fused repetition penalty (grx_constraint.repetition_penalty) every partial
+ * call also copies the raw logits of the row's own tokens ids[r, penalty_skip:T) that
+ * lie inside its slice into grx_chunk.pen_logits (device fp32 [R, pen_stride],
+ * pen_stride >= T - penalty_skip; shared by the calls of a step, contents need no
+ * initialisation), and the step ends with grx_constrained_finish_penalised -- given
+ * the same rows (input_ids, T), constraint and pen_logits -- instead of
+ * grx_constrained_finish; results equal grx_constrained_candidates' with the same
+ * penalty up to fp32 summation order.
  */
 #define GRX_MAX_PARTIAL_SLOTS 4096
 typedef struct grx_chunk {
@@ -267,6 +276,8 @@ typedef struct grx_chunk {
     int32_t n_slots; /* partial slots per row                                       */
     int32_t parts;   /* waves that share one row of the slice (>= 1; see grx_chunk_parts) */
     int32_t first;   /* 1: this call opens the step (exactly one call per step)     */
+    float* pen_logits;  /* repetition penalty only (else null): see above            */
+    int64_t pen_stride;
 } grx_chunk;
 /* a good `parts` for R rows of Vc columns: 1 when the rows alone fill the GPU */
 GRX_API int32_t grx_chunk_parts(int32_t R, int32_t Vc, int32_t dtype);
@@ -277,6 +288,10 @@ GRX_API int grx_constrained_partial(const grx_trie* trie, grx_state* state, cons
 GRX_API int grx_constrained_finish(int32_t R, int32_t n_slots, const float* partials, grx_cand* cand,
                                    int64_t cand_stride, int32_t cmax, const void* workspace, size_t workspace_bytes,
                                    void* stream);
+GRX_API int grx_constrained_finish_penalised(const grx_rows* rows, const grx_constraint* con, int32_t v_total,
+                                             int32_t n_slots, const float* partials, const float* pen_logits,
+                                             int64_t pen_stride, grx_cand* cand, int64_t cand_stride, int32_t cmax,
+                                             const void* workspace, size_t workspace_bytes, void* stream);
 
 /*
  * Kernel timing for benchmarks (no counterpart in the reference).  While

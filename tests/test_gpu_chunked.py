@@ -197,8 +197,8 @@ def test_sliced_step_reports_errors_and_rejects_what_it_cannot_do():
     with pytest.raises(ValueError, match="Failed to find a valid trie prefix match"):
         _feed_all(fixed, bad, scores, bounds)
     # configuration the sliced step does not serve
-    with pytest.raises(_lib.GenrecHipError, match="repetition penalty"):
-        ConstrainedLogitsProcessor(fn, K, 3, None, eos, repetition_penalty=1.1).chunked_step(
+    with pytest.raises(_lib.GenrecHipError, match="assume_normalized"):
+        ConstrainedLogitsProcessor(fn, K, 3, None, eos, assume_normalized=True).chunked_step(
             bad, Candidates(bad.shape[0], 8, dev), V, bounds, torch.float32)
     ok = ConstrainedLogitsProcessor(fn, K, 3, None, eos)
     for wrong in ([(0, 512)], [(0, 512), (500, V)], [(0, 512), (512, V + 1)], [(1, V)]):
@@ -239,6 +239,16 @@ def test_sliced_step_reports_errors_and_rejects_what_it_cannot_do():
     assert call(v_total=10) == -1
     assert lib.grx_constrained_finish(R, 0, partials.data_ptr(), cand.buf.data_ptr(), cand.stride, cand.cmax,
                                       ws.data_ptr(), ws.numel(), None) == -1
+    # a penalised step without the buffer for the penalised tokens' logits, keep_top on slices
+    con.repetition_penalty = 1.1
+    assert call() == -1 and b"pen_logits" in lib.grx_last_error()
+    assert lib.grx_constrained_finish_penalised(C.byref(rows), C.byref(con), V, 4, partials.data_ptr(), None, 0,
+                                                cand.buf.data_ptr(), cand.stride, cand.cmax, ws.data_ptr(),
+                                                ws.numel(), None) == -1
+    con.repetition_penalty = 1.0
+    con.keep_top = 4
+    assert call() == -3 and b"keep_top" in lib.grx_last_error()
+    con.keep_top = 0
     torch.cuda.synchronize()
     assert not bool(cand.buf.any()), "a refused call must not have written anything"
     assert ok._read_state(0)[3] == calls_before, "a refused call must not count as a processor call"
@@ -290,10 +300,11 @@ def test_sliced_first_step_on_one_row_per_group_and_plans_made_ahead():
         assert float((c0[live] - c1[live]).abs().max()) <= 1e-5
 
 
-@pytest.mark.parametrize("kind", ["count", "fixed"])
-def test_generation_with_a_sliced_lm_head_equals_generation_from_whole_logits(kind):
+@pytest.mark.parametrize("kind,penalty", [("count", 1.0), ("fixed", 1.0), ("count", 1.3), ("fixed", 1.1)])
+def test_generation_with_a_sliced_lm_head_equals_generation_from_whole_logits(kind, penalty):
     """constrained_generate(lm_head_slice=...) -- transformer body, LM head slice by slice into the
-    sliced step, one stream or two -- returns the beams of the same loop fed whole logits."""
+    sliced step, one stream or two -- returns the beams of the same loop fed whole logits, with or
+    without the fused repetition penalty."""
     from transformers import Qwen2Config, Qwen2ForCausalLM
 
     from genrec_amd.fixed_hint_logit_processor import FixedHintConstrainedLogitsProcessor
@@ -324,15 +335,83 @@ def test_generation_with_a_sliced_lm_head_equals_generation_from_whole_logits(ki
         rows.append([pad] * (max(lens) - n) + body + prefix)
     prompts = torch.tensor(rows, device=dev)
     mask = (prompts != pad).long()
-    want = constrained_generate(model, prompts, cls(fn, K, 3, prefix, eos), K, 8, attention_mask=mask,
+    kw = {} if penalty == 1.0 else {"repetition_penalty": penalty}
+    want = constrained_generate(model, prompts, cls(fn, K, 3, prefix, eos, **kw), K, 8, attention_mask=mask,
                                 eos_token_id=eos, pad_token_id=pad, length_penalty=0.0)
     live = want.sequences_scores > -1e8
     assert int(live.sum()) >= 12
     for cols, overlap, share in ((64, False, True), (64, True, True), (100, True, False), (V, False, True)):
-        got = constrained_generate(model, prompts, cls(fn, K, 3, prefix, eos), K, 8, attention_mask=mask,
+        got = constrained_generate(model, prompts, cls(fn, K, 3, prefix, eos, **kw), K, 8, attention_mask=mask,
                                    eos_token_id=eos, pad_token_id=pad, length_penalty=0.0, share_prefill=share,
                                    lm_head_slice=cols, lm_head_overlap=overlap)
         assert got.steps == want.steps
         assert torch.equal(got.sequences[live], want.sequences[live]), (cols, overlap, share)
         assert torch.equal(got.beam_indices[live], want.beam_indices[live])
         assert float((got.sequences_scores[live] - want.sequences_scores[live]).abs().max()) <= 1e-4
+
+
+def test_sliced_step_with_the_fused_repetition_penalty_matches_the_transformers_chain():
+    """The recorded chain log_softmax -> transformers' RepetitionPenaltyLogitsProcessor -> reference
+    processor (penalty.npz), through column slices: every slice leaves the raw logits of the rows' own
+    tokens behind, the finishing kernel penalises and renormalises.  Tokens bit for bit; values within
+    1e-5 of the float64 chain and of the whole-row kernel with the same penalty; bf16 slices against a
+    float64 chain over the rounded logits."""
+    import tempfile
+
+    from oracle.processors import ref_repetition_penalty
+
+    from genrec_amd.fixed_hint_logit_processor import FixedHintConstrainedLogitsProcessor
+    from genrec_amd.logit_processor import ConstrainedLogitsProcessor
+    from genrec_amd.synth import ASSISTANT_PREFIX, SidTokenizer, write_index_file
+    from genrec_amd.trie import build_trie_from_index, create_prefix_allowed_tokens_fn
+    from helpers import load_npz
+
+    dev = _dev()
+    data, meta = load_npz("penalty.npz")
+    path = write_index_file("Instruments", tempfile.mkdtemp())
+    tok = SidTokenizer.from_index(path)
+    trie, suffix, pidx = build_trie_from_index(path, tok, prefix=ASSISTANT_PREFIX)
+    fn = create_prefix_allowed_tokens_fn(trie, suffix)
+    K, V, eos = meta["K"], meta["V"], meta["eos"]
+    rng = np.random.default_rng(3)
+    for ci, case in enumerate(meta["cases"]):
+        ids = torch.from_numpy(data[f"{ci}.ids"])
+        logits = torch.randn(ids.shape[0], V, generator=torch.Generator().manual_seed(case["seed"])) * meta["scale"]
+        if case["peaked"]:
+            logits[torch.arange(ids.shape[0]), ids[:, 7]] += 40.0
+        kw = dict(repetition_penalty=case["penalty"], prompt_ignore_length=case["skip"], sync_errors=True)
+
+        def make():
+            if case["processor"] == "count":
+                p = ConstrainedLogitsProcessor(fn, K, pidx, None, eos, **kw)
+                p.count = case["step"]
+                return p
+            return FixedHintConstrainedLogitsProcessor(fn, K, pidx, suffix, eos, **kw)
+
+        n = torch.from_numpy(data[f"{ci}.count"])
+        valid = torch.arange(data[f"{ci}.tok"].shape[1])[None, :] < n[:, None]
+        want_tok = torch.from_numpy(data[f"{ci}.tok"])[valid]
+        exact = torch.from_numpy(data[f"{ci}.val64"])[valid]
+        # slice borders: the SID tokens sit at the top of the vocabulary, the prompt tokens below 151,643,
+        # so penalised tokens and candidates land in different slices, and some slices hold neither
+        cuts = sorted({0, V, 65536, 131072, *rng.integers(151000, V, size=2).tolist()})
+        bounds = list(zip(cuts[:-1], cuts[1:]))
+        order = rng.permutation(len(bounds)).tolist()
+        for dtype in (torch.float32, torch.bfloat16):
+            x = logits.to(dtype).to(dev)
+            whole = make().candidates(ids.to(dev), x)
+            cand = _feed_all(make(), ids.to(dev), x, bounds, order=order)
+            assert torch.equal(cand.count.cpu(), n)
+            cvalid = torch.arange(cand.cmax)[None, :] < n[:, None]
+            assert torch.equal(cand.tokens.cpu()[cvalid], want_tok)
+            got = cand.logp.cpu()[cvalid]
+            wvalid = torch.arange(whole.cmax)[None, :] < n[:, None]
+            assert float((got - whole.logp.cpu()[wvalid]).abs().max()) <= FP32_TOL
+            assert float((cand.logsumexp - whole.logsumexp).abs().max()) <= FP32_TOL
+            if dtype == torch.float32:
+                assert float((got.double() - exact).abs().max()) <= FP32_TOL
+            else:
+                lp64 = torch.log_softmax(logits.to(dtype).double(), dim=-1)
+                e16 = torch.log_softmax(ref_repetition_penalty(ids, lp64, case["penalty"], case["skip"]), dim=-1)
+                rows = torch.arange(ids.shape[0])[:, None].expand_as(cvalid)[cvalid]
+                assert float((got.double() - e16[rows, want_tok.long()]).abs().max()) <= FP32_TOL

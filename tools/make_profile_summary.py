@@ -83,7 +83,9 @@ def main():
                      f"{rp['GBps'] / 80:.1f} % of peak; the streaming kernel reaches "
                      f"{rf['frac_of_read_probe'] * 100:.1f} % of that")
     if cb:
-        lines.append(f"* cpu_baseline ({cb['kind']}, {cb['cores']} threads): {cb['value']:.3f} steps/s ({cb['sample']})")
+        lines.append(f"* cpu_baseline ({cb['kind']}, {cb['cores']} threads): {cb['value']:.3f} steps/s ({cb['sample']})"
+                     + (f"; on 8 threads {cb['at_8_cores']['value']:.3f} steps/s ({cb['at_8_cores']['sample']})"
+                        if cb.get("at_8_cores") else ""))
     if ps:
         for k, v in ps.items():
             lines.append(f"* processor surface {k} (dense [R, V] output): {v['ms_per_call'] * 1e3:.0f} µs "
