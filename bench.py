@@ -222,14 +222,23 @@ def time_processor_surface(args, wl, device, calls=10):
     out = {}
     # third mode: what generate() hands over when nothing runs ahead of the processor -- rows that already
     # are log-softmax values; the processor is told so and only writes (fill + gather of the allowed values)
-    vouched = type(proc)(wl["fn"], args.beams, wl["pidx"], wl["suffix"], wl["tok"].eos_token_id, assume_normalized=True)
+    make = lambda **kw: type(proc)(wl["fn"], args.beams, wl["pidx"], wl["suffix"], wl["tok"].eos_token_id, **kw)
+    vouched = make(assume_normalized=True)
+    # fourth and fifth mode: the processor keeps ONE result tensor for every call (safe under generate(),
+    # which reads the result once per step): a call moves the few finite positions instead of writing
+    # rows x vocab of -inf, so its traffic is the read of the scores -- or, with normalised rows, next to none
+    kept = make(reuse_output=True)
+    kept_vouched = make(reuse_output=True, assume_normalized=True)
+    procs = [proc, vouched, kept, kept_vouched]
     for name, x, p in (("bf16->bf16", wl["logits"][1], proc), ("fp32->fp32", None, proc),
-                       ("fp32->fp32, rows already normalised", None, vouched)):
+                       ("fp32->fp32, rows already normalised", None, vouched),
+                       ("fp32->fp32, one kept result tensor", None, kept),
+                       ("fp32->fp32, rows already normalised, one kept result tensor", None, kept_vouched)):
         if x is None:
             x = wl["logits"][1].float()
-            if p is vouched:
+            if p.assume_normalized:
                 x = torch.log_softmax(x, dim=-1)
-        res = torch.empty_like(x)
+        res = None if p.reuse_output else torch.empty_like(x)
         for i in range(calls + 2):
             if i == 2:
                 torch.cuda.synchronize()
@@ -242,12 +251,15 @@ def time_processor_surface(args, wl, device, calls=10):
         _lib.check(lib.grx_timing_read(C.byref(tot), C.byref(n)))
         lib.grx_timing_enable(0)
         ms = tot.value / max(n.value, 1)
-        nbytes = (1 if p is vouched else 2) * R * V * x.element_size()
-        out[name] = {"ms_per_call": ms, "algorithmic_bytes": nbytes, "achieved_GBps": nbytes / ms / 1e6,
-                     "frac_of_peak": nbytes / ms / 1e6 / HBM_PEAK_GBS}
+        # bytes a call has to move: the scores once unless vouched for, the result once unless kept
+        nbytes = ((0 if p.assume_normalized else 1) + (0 if p.reuse_output else 1)) * R * V * x.element_size()
+        out[name] = {"ms_per_call": ms, "algorithmic_bytes": nbytes,
+                     "achieved_GBps": nbytes / ms / 1e6 if nbytes else None,
+                     "frac_of_peak": nbytes / ms / 1e6 / HBM_PEAK_GBS if nbytes else None}
+        p._kept.clear()
         del res, x
-    proc.check_errors()
-    vouched.check_errors()
+    for p in procs:
+        p.check_errors()
     return out
 
 

@@ -36,6 +36,8 @@ EXPORTED_SYMBOLS = (
     "grx_state_read",
     "grx_workspace_bytes",
     "grx_constrained_logsoftmax",
+    "grx_reuse_bytes",
+    "grx_constrained_logsoftmax_reuse",
     "grx_constrained_candidates",
     "grx_candidate_stride",
     "grx_noalloc_max_rows",
@@ -217,6 +219,12 @@ def _declare(lib: C.CDLL) -> None:
     lib.grx_constrained_logsoftmax.restype = C.c_int
     lib.grx_constrained_logsoftmax.argtypes = [
         vp, vp, C.POINTER(GrxRows), C.POINTER(GrxConstraint), vp, i64, i32, vp, C.c_size_t, vp,
+    ]
+    lib.grx_reuse_bytes.restype = C.c_size_t
+    lib.grx_reuse_bytes.argtypes = [i32]
+    lib.grx_constrained_logsoftmax_reuse.restype = C.c_int
+    lib.grx_constrained_logsoftmax_reuse.argtypes = [
+        vp, vp, C.POINTER(GrxRows), C.POINTER(GrxConstraint), vp, i64, i32, vp, i32, vp, C.c_size_t, vp,
     ]
     lib.grx_constrained_candidates.restype = C.c_int
     lib.grx_constrained_candidates.argtypes = [

@@ -51,6 +51,11 @@ struct MlsArgs {
     const float* row_bias; // ... ranked by logp + row_bias[r] (null: 0), the sum the beam step ranks by
     int* split_count;      // [R] arrival counters, zero between calls
     float2* split_part;    // [R * S] partial (max, sum)
+    // Dense output kept by the caller from call to call: last[r] is the node whose tokens row r of
+    // `out` holds finite values for (written by every such call).  prefilled: `out` is -inf everywhere
+    // else already, so instead of a fill pass the kernel resets just those positions.
+    grx_row_plan* last;
+    int prefilled;
 };
 
 
@@ -258,14 +263,14 @@ __global__ __launch_bounds__(MLS_THREADS) void masked_lsm_kernel(MlsArgs a) {
     // Elements not covered by 16-byte vectors (all of them when !VEC); the last part of a split row.
     // Rows that are not streamed (skip_stream) are only visited here for the -inf fill of an
     // element-wise dense output.
-    if ((!SPLIT || part == a.S - 1) && !(a.skip_stream && (VEC || OUT == OUT_COMPACT))) {
+    if ((!SPLIT || part == a.S - 1) && !(a.skip_stream && (VEC || OUT == OUT_COMPACT || a.prefilled))) {
         const float ninf_f = -INFINITY;
         for (int e = (VEC ? nvec * EPV : 0) + tid; e < a.V; e += MLS_THREADS) {
             if (!a.skip_stream) {
                 float f[1] = {E::to_float(row[e])};
                 accumulate<1>(acc, f);
             }
-            if (VEC) continue;  // pre-filled
+            if (VEC || a.prefilled) continue;  // filled by fill_rows_kernel / still filled from the call before
             if (OUT == OUT_FULL_F32) {
                 reinterpret_cast<float*>(a.out)[(int64_t)r * a.out_stride + e] = ninf_f;
             } else if (OUT == OUT_FULL_SAME) {
@@ -274,15 +279,28 @@ __global__ __launch_bounds__(MLS_THREADS) void masked_lsm_kernel(MlsArgs a) {
         }
     }
 
-    if (OUT != OUT_COMPACT && !VEC) {
-        // The -inf fill of every thread must have reached memory before any thread -- of
-        // any wave -- overwrites an allowed position: each thread waits for its own stores,
-        // then the workgroup meets.  (The barrier inside block_combine cannot stand in for
-        // this one: rows that are not streamed never get there.)
+    typedef typename std::conditional<OUT == OUT_FULL_F32, float, T>::type OT;
+    // An output row kept from the call before: its finite positions -- the tokens of the node recorded
+    // in last[r] -- go back to -inf, which restores the all -inf row a fill pass would have left.
+    auto reset_last = [&]() {
+        if constexpr (OUT != OUT_COMPACT) {
+            const grx_row_plan was = a.last[r];
+            OT* __restrict__ orow = reinterpret_cast<OT*>(a.out) + (int64_t)r * a.out_stride;
+            for (int i = tid; i < was.n; i += MLS_THREADS) {
+                const int tokv = was.code == GRX_RES_EOS ? a.eos : a.tok[was.off + i];
+                orow[tokv] = to_out<DT, OUT>(-INFINITY);
+            }
+        }
+    };
+    if (OUT != OUT_COMPACT && a.prefilled && !SPLIT) reset_last();
+    if (OUT != OUT_COMPACT && (!VEC || (a.prefilled && !SPLIT))) {
+        // The -inf stores of every thread (fill or reset) must have reached memory before any
+        // thread -- of any wave -- overwrites an allowed position: each thread waits for its own
+        // stores, then the workgroup meets.  (The barrier inside block_combine cannot stand in
+        // for this one: rows that are not streamed never get there.)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
-    typedef typename std::conditional<OUT == OUT_FULL_F32, float, T>::type OT;
     MSTAMP(3);
     MaxSum tot;
     if (a.skip_stream) {  // the caller's rows are normalised: max-shifted sum 1 at maximum 0, log-sum-exp 0
@@ -331,6 +349,11 @@ __global__ __launch_bounds__(MLS_THREADS) void masked_lsm_kernel(MlsArgs a) {
         tot.s = sum;
         if (tid == 0)  // ready for the next call
             __hip_atomic_store(&a.split_count[r], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (OUT != OUT_COMPACT && a.prefilled) {  // the emitting workgroup tidies the kept output row
+            reset_last();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
         gather();
     }
     const float log_s = logf(tot.s);
@@ -529,6 +552,14 @@ __global__ __launch_bounds__(MLS_THREADS) void masked_lsm_kernel(MlsArgs a) {
         for (int i = tid + MLS_EARLY * MLS_THREADS; i < c_n; i += MLS_THREADS) {
             const int tok = a.tok[c_off + i];  // an EOS-only row has c_n == 1 and never gets here
             put(tok, final_logp(tok, E::to_float(row[tok]) - tot.m));
+        }
+        if (a.last != nullptr && tid == 0) {  // what this row of `out` now holds, for the next call on it
+            grx_row_plan now;
+            now.code = code;
+            now.off = c_off;
+            now.n = (code >= 0 || code == GRX_RES_EOS) ? c_n : 0;
+            now.pad = 0;
+            a.last[r] = now;
         }
     }
 #ifdef MLS_STAMP
@@ -768,7 +799,7 @@ static int run_step(const char* who, const grx_trie* trie, grx_state* state, con
     }
     const int slot = timing_slot();
     hipEvent_t ev0 = slot >= 0 ? g_ev_start[slot] : nullptr, ev1 = slot >= 0 ? g_ev_stop[slot] : nullptr;
-    if (out_kind != OUT_COMPACT && vec) {
+    if (out_kind != OUT_COMPACT && vec && !a.prefilled) {
         // Dense output, phase 1: -inf everywhere (write-only); the stream kernel then only reads
         // and scatters the allowed positions.  A timed call spans both kernels.
         const int odt = out_kind == OUT_FULL_F32 ? GRX_F32 : rows->dtype;
@@ -812,6 +843,33 @@ extern "C" int grx_constrained_logsoftmax(const grx_trie* trie, grx_state* state
     memset(&a, 0, sizeof(a));
     a.out = out;
     a.out_stride = out_stride;
+    const int kind = (out_dtype == GRX_F32) ? OUT_FULL_F32 : OUT_FULL_SAME;
+    const bool out_aligned = rows_16b_aligned(out, out_stride, dtype_size(out_dtype));
+    return run_step(who, trie, state, rows, con, a, kind, out_aligned, workspace, workspace_bytes,
+                    (hipStream_t)stream);
+}
+
+extern "C" size_t grx_reuse_bytes(int32_t R) { return R > 0 ? (size_t)R * sizeof(grx_row_plan) : 0; }
+
+extern "C" int grx_constrained_logsoftmax_reuse(const grx_trie* trie, grx_state* state, const grx_rows* rows,
+                                                const grx_constraint* con, void* out, int64_t out_stride,
+                                                int32_t out_dtype, void* last_rows, int32_t fresh, void* workspace,
+                                                size_t workspace_bytes, void* stream) {
+    const char* who = "grx_constrained_logsoftmax_reuse";
+    GRX_REQUIRE(rows != nullptr, GRX_E_INVALID, "%s: null rows", who);
+    GRX_REQUIRE(out_dtype == GRX_F32 || out_dtype == rows->dtype, GRX_E_UNSUPPORTED,
+                "%s: output must be fp32 or the input element type", who);
+    GRX_REQUIRE(rows->R == 0 || (out != nullptr && out_stride >= rows->V), GRX_E_INVALID, "%s: bad output", who);
+    GRX_REQUIRE(out != rows->scores || rows->R == 0, GRX_E_INVALID, "%s: out must not alias scores", who);
+    GRX_REQUIRE(fresh == 0 || fresh == 1, GRX_E_INVALID, "%s: fresh must be 0 or 1", who);
+    GRX_REQUIRE(rows->R == 0 || (last_rows != nullptr && ((uintptr_t)last_rows & 15u) == 0), GRX_E_INVALID,
+                "%s: last_rows must be a 16-byte aligned device buffer of grx_reuse_bytes(R) bytes", who);
+    MlsArgs a;
+    memset(&a, 0, sizeof(a));
+    a.out = out;
+    a.out_stride = out_stride;
+    a.last = reinterpret_cast<grx_row_plan*>(last_rows);
+    a.prefilled = fresh ? 0 : 1;
     const int kind = (out_dtype == GRX_F32) ? OUT_FULL_F32 : OUT_FULL_SAME;
     const bool out_aligned = rows_16b_aligned(out, out_stride, dtype_size(out_dtype));
     return run_step(who, trie, state, rows, con, a, kind, out_aligned, workspace, workspace_bytes,

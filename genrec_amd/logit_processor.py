@@ -224,6 +224,7 @@ class _TrieConstrainedBase(LogitsProcessor):
         repetition_penalty: float = 1.0,
         prompt_ignore_length: int = 0,
         assume_normalized: bool = False,
+        reuse_output: bool = False,
     ):
         self._prefix_allowed_tokens_fn = prefix_allowed_tokens_fn
         self._num_beams = num_beams
@@ -253,6 +254,13 @@ class _TrieConstrainedBase(LogitsProcessor):
         self.assume_normalized = bool(assume_normalized)
         if self.assume_normalized and self.repetition_penalty != 1.0:
             raise ValueError("assume_normalized cannot be combined with the fused repetition penalty")
+        # Extension: `__call__` returns the SAME tensor every time (per device and shape) instead of a
+        # new one -- the next call overwrites what the previous one returned.  transformers' beam loop
+        # reads the result once (it adds the running scores into a new tensor, and clones what it keeps
+        # for output_scores), so this is safe there; it is not for a caller that holds on to results.
+        # The kernel then only moves the few finite positions instead of writing rows x vocab of -inf.
+        self.reuse_output = bool(reuse_output)
+        self._kept: dict[int, dict] = {}
         self._trie: Optional[FlatTrie] = None
         self._states: dict[int, _DeviceState] = {}
         self._workspaces: dict[int, torch.Tensor] = {}
@@ -412,7 +420,19 @@ class _TrieConstrainedBase(LogitsProcessor):
         and lets bf16 logits produce fp32 log-probs."""
         rows, ids_keep, scores_keep = self._rows(input_ids, scores)
         index = self._device_index(scores_keep)
-        if out is None:
+        kept = None
+        if out is None and self.reuse_output and rows.R > 0:
+            key = (tuple(scores_keep.shape), scores_keep.dtype, self.eos_token_id)
+            kept = self._kept.get(index)
+            if kept is None or kept["key"] != key:
+                self._kept.pop(index, None)  # release the old tensor before allocating the new one
+                kept = {"key": key, "fresh": 1,
+                        "out": torch.empty_like(scores_keep, memory_format=torch.contiguous_format),
+                        "last": torch.zeros(int(_lib.lib().grx_reuse_bytes(rows.R)), dtype=torch.uint8,
+                                            device=scores_keep.device)}
+                self._kept[index] = kept
+            out = kept["out"]
+        elif out is None:
             out = torch.empty_like(scores_keep, memory_format=torch.contiguous_format)
         else:
             _lib.require_cuda(out, "out")
@@ -425,20 +445,30 @@ class _TrieConstrainedBase(LogitsProcessor):
             st = self._state(index)
             ws = self._workspace(index, rows.R)
             con = self._constraint()
-            _lib.check(
-                _lib.lib().grx_constrained_logsoftmax(
-                    self.trie.device_handle(scores_keep.device),
-                    st.ptr,
-                    C.byref(rows),
-                    C.byref(con),
-                    out.data_ptr(),
-                    out.stride(0) if out.shape[0] > 1 else out.shape[1],
-                    _lib.torch_dtype_code(out.dtype),
-                    ws.data_ptr(),
-                    ws.numel(),
-                    _lib.current_stream_ptr(scores_keep.device),
+            if kept is not None:
+                _lib.check(
+                    _lib.lib().grx_constrained_logsoftmax_reuse(
+                        self.trie.device_handle(scores_keep.device), st.ptr, C.byref(rows), C.byref(con),
+                        out.data_ptr(), out.shape[1], _lib.torch_dtype_code(out.dtype), kept["last"].data_ptr(),
+                        kept["fresh"], ws.data_ptr(), ws.numel(), _lib.current_stream_ptr(scores_keep.device),
+                    )
                 )
-            )
+                kept["fresh"] = 0  # enqueued: from here on the tensor and its record belong together
+            else:
+                _lib.check(
+                    _lib.lib().grx_constrained_logsoftmax(
+                        self.trie.device_handle(scores_keep.device),
+                        st.ptr,
+                        C.byref(rows),
+                        C.byref(con),
+                        out.data_ptr(),
+                        out.stride(0) if out.shape[0] > 1 else out.shape[1],
+                        _lib.torch_dtype_code(out.dtype),
+                        ws.data_ptr(),
+                        ws.numel(),
+                        _lib.current_stream_ptr(scores_keep.device),
+                    )
+                )
         self._active = index
         if self.sync_errors_dense:
             self.check_errors()
@@ -588,11 +618,12 @@ class ConstrainedLogitsProcessor(_TrieConstrainedBase):
         repetition_penalty: float = 1.0,
         prompt_ignore_length: int = 0,
         assume_normalized: bool = False,
+        reuse_output: bool = False,
     ):
         super().__init__(
             prefix_allowed_tokens_fn, num_beams, prefix_index, prefix_ids, eos_token_id, sync_errors=sync_errors,
             repetition_penalty=repetition_penalty, prompt_ignore_length=prompt_ignore_length,
-            assume_normalized=assume_normalized,
+            assume_normalized=assume_normalized, reuse_output=reuse_output,
         )
         self.initial_count = int(initial_count)
         self._count_host = self.initial_count  # value to push to a device on first use / after a set

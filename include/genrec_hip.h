@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define GRX_ABI_VERSION 10
+#define GRX_ABI_VERSION 11
 
 #if defined(GRX_BUILDING)
 #define GRX_API __attribute__((visibility("default")))
@@ -183,6 +183,27 @@ GRX_API size_t grx_workspace_bytes(int32_t R);
 GRX_API int grx_constrained_logsoftmax(const grx_trie* trie, grx_state* state, const grx_rows* rows,
                                const grx_constraint* con, void* out, int64_t out_stride, int32_t out_dtype,
                                void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * The same call for a caller that keeps ONE output tensor and hands it to every call (no
+ * counterpart in the reference, whose logit_processor.py:31,49 builds a new mask and a new
+ * result per call -- transformers' beam loop reads the result once and drops it, so one tensor
+ * can serve every step).  A dense result is -inf except at the few allowed positions of each
+ * row; when `out` still holds the previous call's result, writing V x -inf again is all waste:
+ * this form resets just the positions the previous call made finite and writes the new ones,
+ * so the call costs the read of `scores` alone (with assume_normalized: next to nothing).
+ * last_rows: device buffer of grx_reuse_bytes(R) bytes that travels with `out` -- the library
+ * records in it which trie node every row of `out` currently shows.  fresh = 1: `out` holds
+ * anything (first call, new tensor, other shape): it is filled like grx_constrained_logsoftmax
+ * does and last_rows is initialised; fresh = 0: `out` and last_rows are exactly as the previous
+ * call on them left them (same R, V, out_dtype, eos_token_id, trie) and nobody wrote to either.
+ * Everything else as grx_constrained_logsoftmax.
+ */
+GRX_API size_t grx_reuse_bytes(int32_t R);
+GRX_API int grx_constrained_logsoftmax_reuse(const grx_trie* trie, grx_state* state, const grx_rows* rows,
+                                             const grx_constraint* con, void* out, int64_t out_stride,
+                                             int32_t out_dtype, void* last_rows, int32_t fresh, void* workspace,
+                                             size_t workspace_bytes, void* stream);
 
 /*
  * Compact candidate rows, the hand-off between the fused log-softmax and the
