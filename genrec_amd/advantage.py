@@ -204,11 +204,14 @@ def rollout_advantages(local_rewards_per_func: torch.Tensor, reward_weights: tor
         )
     pending = _start_gather(local_rewards_per_func)
     n_local = local_rewards_per_func.shape[0]
-    if scale_rewards == "batch" and pending[0] is not None:
+    # a collective ran (or is running) whenever what comes back is not the local tensor itself -- with
+    # torch.distributed there is a work handle to wait for, with the library's communicator there is none
+    gathered = pending[1] is not local_rewards_per_func
+    if scale_rewards == "batch" and gathered:
         res = RolloutAdvantages(None, (None, None, None), pending, reward_weights, num_generations, scale_rewards, eps)
         rewards, adv, mean, std = res.wait_global()
         if process_index is None:
-            process_index = dist.get_rank()
+            process_index = _native_comm.rank if _native_comm is not None else dist.get_rank()
         sl = slice(process_index * n_local, (process_index + 1) * n_local)
         res.local_advantages = adv[sl]
         res.local_rewards, res.local_group_mean, res.local_std = rewards[sl], mean[sl], std[sl]
@@ -216,7 +219,7 @@ def rollout_advantages(local_rewards_per_func: torch.Tensor, reward_weights: tor
     rewards, adv, mean, std = group_advantages(local_rewards_per_func, reward_weights, num_generations,
                                                scale_rewards, eps)
     res = RolloutAdvantages(adv, (rewards, mean, std), pending, reward_weights, num_generations, scale_rewards, eps)
-    if pending[0] is None and pending[2] is None and pending[1] is local_rewards_per_func:  # one process, no collective
+    if not gathered:  # one process, no collective: the local statistics are the global ones
         res._global = (rewards, adv, mean, std)
     return res
 
@@ -236,6 +239,6 @@ def rollout_score(scorer, completion_ids: torch.Tensor, gt_ids: torch.Tensor, re
                                                                   scale_rewards, hint_ids, want, out, eps)
     pending = _start_gather(rpf)
     res = RolloutAdvantages(adv, (rewards, mean, std), pending, reward_weights, scorer.num_beams, scale_rewards, eps)
-    if pending[0] is None and pending[2] is None and pending[1] is rpf:
+    if pending[1] is rpf:  # no collective ran
         res._global = (rewards, adv, mean, std)
     return res

@@ -43,3 +43,46 @@ def test_the_librarys_own_rccl_communicator_with_one_rank():
                          capture_output=True, text=True, timeout=200)
     assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-4000:]
     assert "native rccl ok" in run.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scale", ["group", "batch", "none"])
+def test_exchange_through_a_stream_ordered_communicator_uses_the_rows_of_all_ranks(scale):
+    """A communicator whose all-gather is ordered by the stream hands back no work handle (the library's
+    own RCCL communicator): the exchange step must still normalise "batch" over the rows of all ranks.
+    The second rank is played by a stand-in whose all-gather puts another rank's rewards in front."""
+    import torch
+
+    from genrec_amd import advantage
+
+    assert torch.cuda.is_available()
+    dev = torch.device("cuda", 0)
+    K, G = 4, 6
+    torch.manual_seed(3)
+    other = torch.randn(G * K, 2, device=dev)
+    mine = torch.randn(G * K, 2, device=dev) * 3 + 1
+    w = torch.tensor([1.0, 0.5], device=dev)
+
+    class TwoRanks:
+        n_ranks, rank = 2, 1
+
+        def allgather(self, t):
+            return torch.cat([other, t.contiguous()], dim=0)
+
+    want = advantage.group_advantages(torch.cat([other, mine]), w, K, scale)
+    advantage.use_native_comm(TwoRanks())
+    try:
+        res = advantage.rollout_advantages(mine, w, K, scale)
+        local, all_adv, rewards, mean, std = res
+    finally:
+        advantage.use_native_comm(None)
+    sl = slice(G * K, 2 * G * K)
+    assert torch.equal(all_adv, want[1]) and torch.equal(rewards, want[0])
+    assert torch.equal(mean, want[2]) and torch.equal(std, want[3])
+    if scale == "batch":
+        assert torch.equal(local, want[1][sl])
+        alone = advantage.group_advantages(mine, w, K, scale)[1]
+        assert not torch.equal(local, alone), "the batch std must come from both ranks' rows"
+    else:
+        assert float((local - want[1][sl]).abs().max()) <= 1e-6
+    assert torch.equal(res.gathered_rewards_per_func(), torch.cat([other, mine]))
