@@ -82,6 +82,10 @@ def main():
                      f"{rp['launches']} launches): {rp['ms'] * 1e3:.1f} µs = {rp['GBps']:.0f} GB/s = "
                      f"{rp['GBps'] / 80:.1f} % of peak; the streaming kernel reaches "
                      f"{rf['frac_of_read_probe'] * 100:.1f} % of that")
+    if rf.get("settle"):
+        st = rf["settle"]
+        lines.append(f"* before the warm-up the run waited {st['waited_s']} s for the GPU's read rate to settle "
+                     f"(probe {st['probe_GBps_first']:.0f} -> {st['probe_GBps_last']:.0f} GB/s, target {st['target_GBps']:.0f})")
     if cb:
         lines.append(f"* cpu_baseline ({cb['kind']}, {cb['cores']} threads): {cb['value']:.3f} steps/s ({cb['sample']})"
                      + (f"; on 8 threads {cb['at_8_cores']['value']:.3f} steps/s ({cb['at_8_cores']['sample']})"
