@@ -302,6 +302,9 @@ def settle(wl, device, patience_s=10.0, cap_s=45.0):
     The read probe is sampled twice a second until four samples in a row reach the rate of an idle part, or
     it has not improved by 0.5 % for `patience_s`, or `cap_s` have passed.  What was seen goes into the result line.
     """
+    x = wl["logits"][min(1, len(wl["logits"]) - 1)]
+    if x.numel() * x.element_size() < (1 << 30):
+        return None  # a launch this small never reaches the idle rate: nothing to compare against
     t0 = time.perf_counter()
     first = best = last = time_read_probe(wl, device, launches=6)["GBps"]
     best_at = 0.0
