@@ -9,8 +9,8 @@ mkdir -p $out
 timeout -k 10 400 python3 bench.py > $out/bench.json 2> $out/bench.err
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -o bench -- \
-    python3 $R/bench.py --no-cpu-baseline --no-processor-surface > $out/prof.log 2>&1
-small="--steps 10 --warmup 5 --no-cpu-baseline --no-processor-surface --no-kernel-timing"
+    python3 $R/bench.py --no-cpu-baseline --no-processor-surface --no-settle > $out/prof.log 2>&1
+small="--steps 10 --warmup 5 --no-cpu-baseline --no-processor-surface --no-kernel-timing --no-settle"
 timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -o pmc -- python3 $R/bench.py $small > $out/pmc_fetch.log 2>&1
 timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -o pmc -- python3 $R/bench.py $small > $out/pmc_write.log 2>&1
 cd $R

@@ -5,9 +5,9 @@
         gpurun_out/r1_pmc_fetch/pmc_counter_collection.csv gpurun_out/r1_pmc_write/pmc_counter_collection.csv
 
 Inputs: the JSON line of `python bench.py`, the kernel stats of
-`rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --no-processor-surface`, and the counter
+`rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --no-processor-surface --no-settle`, and the counter
 files of two separate passes `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` over
-`python3 bench.py --steps 10 --warmup 5 --no-cpu-baseline --no-processor-surface --no-kernel-timing`.
+`python3 bench.py --steps 10 --warmup 5 --no-cpu-baseline --no-processor-surface --no-kernel-timing --no-settle`.
 """
 import collections
 import csv
@@ -51,7 +51,7 @@ def main():
         "read_corrected": fetch, "write": write, "total": fetch + write, "algorithmic": alg,
         "note": "FETCH_SIZE x 1024 x 2 (gfx950 reports exactly half the bytes of a 16-B-per-lane coalesced "
                 "stream) + WRITE_SIZE x 1024; separate --pmc passes of: python3 bench.py --steps 10 --warmup 5 "
-                "--no-cpu-baseline --no-processor-surface --no-kernel-timing"}
+                "--no-cpu-baseline --no-processor-surface --no-kernel-timing --no-settle"}
     with open(os.path.join(out_dir, f"{tag}_pmc_summary.json"), "w") as f:
         json.dump(pmc, f, indent=1)
 
@@ -95,7 +95,7 @@ def main():
             lines.append(f"* processor surface {k} (dense [R, V] output): {v['ms_per_call'] * 1e3:.0f} µs per call"
                          + (f" = {v['achieved_GBps']:.0f} GB/s = {v['frac_of_peak'] * 100:.1f} % of peak on "
                             f"{v['algorithmic_bytes'] / 1e9:.1f} GB" if v.get("algorithmic_bytes") else ""))
-    lines += ["", "`rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --no-processor-surface` "
+    lines += ["", "`rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --no-processor-surface --no-settle` "
               f"(`{tag}_bench_kernel_stats.csv`; the `at::native` rows are the synthetic-logit generation before the "
               "timed region):", ""] + table + [""]
     with open(os.path.join(out_dir, f"{tag}_summary.md"), "w") as f:
