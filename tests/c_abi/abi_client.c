@@ -267,6 +267,51 @@ static int gpu_checks(void) {
         free(h_again);
     }
 
+    /* the dense form, into a new buffer and into one kept from call to call: the second kept call
+     * (rows moved one level down the trie) must leave exactly what a fresh call leaves */
+    {
+        const size_t out_bytes = sizeof(float) * NR * (size_t)NV;
+        float* h_fresh = (float*)malloc(out_bytes);
+        float* h_kept = (float*)malloc(out_bytes);
+        int64_t* h_ids2 = (int64_t*)malloc(sizeof(int64_t) * NR * (NT + 1));
+        void *d_fresh, *d_kept, *d_last, *d_ids2;
+        grx_rows deeper = rows;
+        int call;
+        CHECK(hipMalloc(&d_fresh, out_bytes) == 0 && hipMalloc(&d_kept, out_bytes) == 0 &&
+                  hipMalloc(&d_last, grx_reuse_bytes(NR)) == 0 && hipMalloc(&d_ids2, sizeof(int64_t) * NR * (NT + 1)) == 0,
+              "hipMalloc dense outputs");
+        CHECK(hipMemset(d_kept, 0x5A, out_bytes) == 0, "scribble");
+        for (r = 0; r < NR; ++r) {  /* the same rows one token further: the first allowed token appended */
+            memcpy(h_ids2 + (size_t)r * (NT + 1), h_ids + (size_t)r * NT, sizeof(int64_t) * NT);
+            h_ids2[(size_t)r * (NT + 1) + NT] = allowed[r % 4];
+        }
+        CHECK(hipMemcpy(d_ids2, h_ids2, sizeof(int64_t) * NR * (NT + 1), 1) == 0, "upload deeper rows");
+        deeper.input_ids = (const int64_t*)d_ids2; deeper.ids_stride = NT + 1; deeper.T = NT + 1;
+        for (call = 0; call < 2; ++call) {
+            const grx_rows* now = call == 0 ? &rows : &deeper;
+            size_t n_finite = 0;
+            CHECK(grx_state_set_count(state, call, NULL) == GRX_OK, "grx_state_set_count");
+            CHECK(grx_constrained_logsoftmax(trie, state, now, &con, d_fresh, NV, GRX_F32, d_ws, ws_bytes, NULL) == GRX_OK,
+                  "grx_constrained_logsoftmax");
+            CHECK(grx_state_set_count(state, call, NULL) == GRX_OK, "grx_state_set_count");
+            CHECK(grx_constrained_logsoftmax_reuse(trie, state, now, &con, d_kept, NV, GRX_F32, d_last, call == 0, d_ws,
+                                                   ws_bytes, NULL) == GRX_OK,
+                  "grx_constrained_logsoftmax_reuse");
+            CHECK(grx_state_read(state, st, NULL) == GRX_OK && st[1] == GRX_ROWERR_NONE, "no row error");
+            CHECK(hipMemcpy(h_fresh, d_fresh, out_bytes, 2) == 0 && hipMemcpy(h_kept, d_kept, out_bytes, 2) == 0,
+                  "download dense outputs");
+            CHECK(memcmp(h_fresh, h_kept, out_bytes) == 0, "the kept output equals a fresh one, bit for bit");
+            for (v = 0; v < NR * NV; ++v) n_finite += isfinite(h_kept[v]) ? 1 : 0;
+            CHECK(n_finite > 0 && n_finite <= (size_t)NR * 4, "a few finite positions per row, -inf elsewhere");
+            printf("dense_kept_call_%d_finite=%zu\n", call, n_finite);
+        }
+        CHECK(grx_constrained_logsoftmax_reuse(trie, state, &rows, &con, d_kept, NV, GRX_F32, NULL, 0, d_ws, ws_bytes,
+                                               NULL) == GRX_E_INVALID,
+              "the kept form needs its row record");
+        hipFree(d_fresh); hipFree(d_kept); hipFree(d_last); hipFree(d_ids2);
+        free(h_fresh); free(h_kept); free(h_ids2);
+    }
+
     /* the beam step over those candidates: at step 0 only beam 0 of a group is live */
     memset(&step, 0, sizeof(step));
     step.B = NB; step.K = NK; step.V = NV; step.n_keep = 2 * NK; step.cmax = NCMAX;

@@ -67,3 +67,5 @@ def test_plain_c_client_decodes_one_step_on_the_gpu(tmp_path):
     assert int(facts["beam_step_groups_checked"]) == 3
     assert int(facts["noalloc_rows_identical"]) == 12
     assert float(facts["sliced_max_abs_logp_difference"]) <= 1e-5
+    # dense form kept from call to call == a fresh dense result, on both calls (4 tokens, then 1 per row)
+    assert int(facts["dense_kept_call_0_finite"]) == 48 and int(facts["dense_kept_call_1_finite"]) == 12
