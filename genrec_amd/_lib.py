@@ -57,6 +57,7 @@ EXPORTED_SYMBOLS = (
     "grx_hit_ranks",
     "grx_group_advantage",
     "grx_group_normalize_tokenwise",
+    "grx_token_prefix_advantages",
     "grx_comm_unique_id",
     "grx_comm_create",
     "grx_comm_destroy",
@@ -104,6 +105,36 @@ class GrxChunk(C.Structure):
         ("first", C.c_int32),
         ("pen_logits", C.c_void_p),
         ("pen_stride", C.c_int64),
+    ]
+
+
+class GrxTokenPrefixArgs(C.Structure):
+    _fields_ = [
+        ("completion_ids", C.c_void_p),
+        ("ids_stride", C.c_int64),
+        ("completion_mask", C.c_void_p),
+        ("gt_ids", C.c_void_p),
+        ("gt_stride", C.c_int64),
+        ("gt_len", C.c_void_p),
+        ("ndcg", C.c_void_p),
+        ("rank_weights", C.c_void_p),
+        ("R", C.c_int32),
+        ("Tc", C.c_int32),
+        ("K", C.c_int32),
+        ("eos_token_id", C.c_int32),
+        ("normalize", C.c_int32),
+        ("total_token_normalize", C.c_int32),
+        ("has_ndcg", C.c_int32),
+        ("error_token_penalty", C.c_int32),
+        ("rank_offset", C.c_int32),
+        ("prefix_weight", C.c_float),
+        ("ndcg_weight", C.c_float),
+        ("eps", C.c_float),
+        ("token_rewards", C.c_void_p),
+        ("seq_rewards", C.c_void_p),
+        ("error_mask", C.c_void_p),
+        ("scratch", C.c_void_p),
+        ("token_advantages", C.c_void_p),
     ]
 
 
@@ -281,6 +312,8 @@ def _declare(lib: C.CDLL) -> None:
     lib.grx_comm_allgather.argtypes = [vp, vp, vp, C.c_size_t, vp]
     lib.grx_group_normalize_tokenwise.restype = C.c_int
     lib.grx_group_normalize_tokenwise.argtypes = [vp, vp, i32, i32, i32, f32, vp, vp]
+    lib.grx_token_prefix_advantages.restype = C.c_int
+    lib.grx_token_prefix_advantages.argtypes = [C.POINTER(GrxTokenPrefixArgs), vp]
 
 
 def lib() -> C.CDLL:

@@ -387,3 +387,170 @@ extern "C" int grx_group_normalize_tokenwise(const float* values, const float* m
     GRX_CHECK_HIP(hipGetLastError());
     return GRX_OK;
 }
+
+// ------------------------------------------- token-level prefix advantages ---
+// The scoring of the token-level trainer (token_prefix_grpo_trainer.py:107-149, 196-278) for the rows
+// of one rank.  Thread = row, a workgroup holds whole groups of K rows.  Every thread matches its
+// completion against its ground truth IN TOKEN SPACE -- valid positions are those with mask > 0, a
+// terminal EOS takes no part -- which gives the row's token rewards (1/len(gt) or 1 on the matched
+// prefix), its sequence reward (their sum) and its error-token mask (valid positions behind the
+// matched prefix).  Then, per group:
+//  * total_token_normalize: raw token rewards  w_p * prefix + w_n * ndcg_tok  go to `scratch`
+//    (ndcg_tok: nothing / rank penalty of the row on its error tokens if any row of the group matched
+//    at all / the row's NDCG reward on every valid token) and grx_token_prefix_advantages normalises
+//    them per (group, position) with the mask-aware kernel above;
+//  * otherwise: sequence rewards are normalised per group (mean, unbiased std, fp64 sums) and spread
+//    over the matched tokens in proportion to their token rewards, plus the normalised NDCG reward
+//    on every valid token.
+struct TokenPrefixArgs {
+    grx_token_prefix_args u;
+    int rows_per_block;
+};
+
+__global__ __launch_bounds__(SC_THREADS) void token_prefix_kernel(TokenPrefixArgs a) {
+    __shared__ float s_seq[SC_THREADS];
+    __shared__ float s_ndcg[SC_THREADS];
+    const grx_token_prefix_args& u = a.u;
+    const int t = threadIdx.x;
+    const int r = blockIdx.x * a.rows_per_block + t;
+    const bool active = t < a.rows_per_block && r < u.R;
+    const int Tc = u.Tc, K = u.K;
+    float seq = 0.f;
+    int matched = 0, n_eff = 0;
+    double per_tok = 1.0;
+    if (active) {
+        const int64_t* __restrict__ ids = u.completion_ids + (int64_t)r * u.ids_stride;
+        const float* __restrict__ mask = u.completion_mask + (int64_t)r * Tc;
+        const int64_t* __restrict__ gt = u.gt_ids + (int64_t)r * u.gt_stride;
+        const int gt_len = u.gt_len[r];
+        int nv = 0;
+        int64_t last = -1;
+        for (int p = 0; p < Tc; ++p)
+            if (mask[p] > 0.f) {
+                ++nv;
+                last = ids[p];
+            }
+        n_eff = (nv > 0 && u.eos_token_id >= 0 && last == (int64_t)u.eos_token_id) ? nv - 1 : nv;
+        per_tok = (u.normalize && gt_len > 0) ? 1.0 / (double)gt_len : 1.0;
+        const float per_tok_f = (float)per_tok;
+        bool matching = true;
+        int j = 0;
+        for (int p = 0; p < Tc; ++p) {
+            float rew = 0.f, err = 0.f;
+            if (mask[p] > 0.f) {
+                if (j < n_eff) {
+                    if (matching && j < gt_len && ids[p] == gt[j]) {
+                        rew = per_tok_f;
+                        ++matched;
+                    } else {
+                        matching = false;
+                        err = 1.f;
+                    }
+                }
+                ++j;
+            }
+            if (u.token_rewards) u.token_rewards[(int64_t)r * Tc + p] = rew;
+            if (u.error_mask) u.error_mask[(int64_t)r * Tc + p] = err;
+        }
+        seq = matched > 0 ? (float)((double)matched * per_tok) : 0.f;
+        if (u.seq_rewards) u.seq_rewards[r] = seq;
+    }
+    s_seq[t] = seq;
+    s_ndcg[t] = (active && u.has_ndcg && u.ndcg) ? u.ndcg[r] : 0.f;
+    __syncthreads();
+    if (!active) return;
+    const int g0 = (t / K) * K;
+    const float* __restrict__ mask = u.completion_mask + (int64_t)r * Tc;
+    const int64_t* __restrict__ ids = u.completion_ids + (int64_t)r * u.ids_stride;
+    const int64_t* __restrict__ gt = u.gt_ids + (int64_t)r * u.gt_stride;
+    const int gt_len = u.gt_len[r];
+    const float per_tok_f = (float)per_tok;
+    // the row's token rewards / error mask again, position by position (cheaper than keeping them)
+    auto for_each_position = [&](auto&& body) {
+        bool matching = true;
+        int j = 0;
+        for (int p = 0; p < Tc; ++p) {
+            float rew = 0.f, err = 0.f;
+            if (mask[p] > 0.f) {
+                if (j < n_eff) {
+                    if (matching && j < gt_len && ids[p] == gt[j]) rew = per_tok_f;
+                    else {
+                        matching = false;
+                        err = 1.f;
+                    }
+                }
+                ++j;
+            }
+            body(p, rew, err, mask[p]);
+        }
+    };
+    if (u.total_token_normalize) {
+        float has_prefix = 0.f;
+        for (int k = 0; k < K; ++k) has_prefix = s_seq[g0 + k] > 0.f ? 1.f : has_prefix;
+        const float rank = (u.has_ndcg && u.error_token_penalty) ? u.rank_weights[(r + u.rank_offset) % K] : 0.f;
+        const float nd = s_ndcg[t];
+        float* __restrict__ out = u.scratch + (int64_t)r * Tc;
+        for_each_position([&](int p, float rew, float err, float m) {
+            float ndcg_tok = 0.f;
+            if (u.has_ndcg) ndcg_tok = u.error_token_penalty ? __fmul_rn(__fmul_rn(rank, err), has_prefix) : __fmul_rn(nd, m);
+            out[p] = __fadd_rn(__fmul_rn(u.prefix_weight, rew), __fmul_rn(u.ndcg_weight, ndcg_tok));
+        });
+        return;
+    }
+    // sequence-then-distribute
+    auto group_normalised = [&](const float* s_val) {
+        double s = 0.0;
+        for (int k = 0; k < K; ++k) s += (double)s_val[g0 + k];
+        const double mean = s / (double)K;
+        double q = 0.0;
+        for (int k = 0; k < K; ++k) {
+            const double d = (double)s_val[g0 + k] - mean;
+            q += d * d;
+        }
+        const float sd = (float)sqrt(q / (double)(K - 1));
+        return (s_val[t] - (float)mean) / (sd + u.eps);
+    };
+    const float adv_prefix = group_normalised(s_seq);
+    const float adv_ndcg = u.has_ndcg ? group_normalised(s_ndcg) : 0.f;
+    float mass = 0.f;
+    for_each_position([&](int, float rew, float, float) { mass += rew; });
+    const float scale = __fmul_rn(u.prefix_weight, adv_prefix);
+    const float spread = __fmul_rn(u.ndcg_weight, adv_ndcg);
+    float* __restrict__ out = u.token_advantages + (int64_t)r * Tc;
+    for_each_position([&](int p, float rew, float, float m) {
+        const float dist = mass > 0.f ? rew / (mass + 1e-8f) : 0.f;
+        float v = __fmul_rn(scale, dist);
+        if (u.has_ndcg) v = __fadd_rn(v, __fmul_rn(spread, m));
+        out[p] = v;
+    });
+}
+
+extern "C" int grx_token_prefix_advantages(const grx_token_prefix_args* args, void* stream) {
+    const char* who = "grx_token_prefix_advantages";
+    GRX_REQUIRE(args != nullptr, GRX_E_INVALID, "%s: null args", who);
+    const grx_token_prefix_args& u = *args;
+    GRX_REQUIRE(u.R >= 0 && u.Tc >= 0 && u.K >= 1, GRX_E_INVALID, "%s: bad shape", who);
+    GRX_REQUIRE(u.K <= SC_THREADS, GRX_E_UNSUPPORTED, "%s: at most %d rows per group", who, SC_THREADS);
+    GRX_REQUIRE(u.R % u.K == 0, GRX_E_INVALID, "%s: %d rows do not split into groups of %d", who, u.R, u.K);
+    if (u.R == 0 || u.Tc == 0) return GRX_OK;
+    GRX_REQUIRE(u.completion_ids && u.completion_mask && u.gt_ids && u.gt_len && u.token_advantages, GRX_E_INVALID,
+                "%s: null pointer", who);
+    GRX_REQUIRE(u.ids_stride >= u.Tc && u.gt_stride >= 0, GRX_E_INVALID, "%s: bad strides", who);
+    GRX_REQUIRE(!u.total_token_normalize || u.scratch, GRX_E_INVALID,
+                "%s: total_token_normalize needs scratch [R, Tc]", who);
+    GRX_REQUIRE(!(u.has_ndcg && u.error_token_penalty && u.total_token_normalize) || u.rank_weights, GRX_E_INVALID,
+                "%s: the error-token penalty needs rank_weights [K]", who);
+    GRX_REQUIRE(!u.has_ndcg || (u.total_token_normalize && u.error_token_penalty) || u.ndcg, GRX_E_INVALID,
+                "%s: has_ndcg needs the rows' NDCG rewards", who);
+    GRX_REQUIRE(u.rank_offset >= 0, GRX_E_INVALID, "%s: rank_offset must be >= 0", who);
+    TokenPrefixArgs a;
+    a.u = u;
+    a.rows_per_block = (SC_THREADS / u.K) * u.K;
+    hipLaunchKernelGGL(token_prefix_kernel, dim3((u.R + a.rows_per_block - 1) / a.rows_per_block), dim3(SC_THREADS), 0,
+                       (hipStream_t)stream, a);
+    GRX_CHECK_HIP(hipGetLastError());
+    if (u.total_token_normalize)
+        return grx_group_normalize_tokenwise(u.scratch, u.completion_mask, u.R, u.Tc, u.K, u.eps, u.token_advantages,
+                                             stream);
+    return GRX_OK;
+}

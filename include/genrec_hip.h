@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define GRX_ABI_VERSION 11
+#define GRX_ABI_VERSION 12
 
 #if defined(GRX_BUILDING)
 #define GRX_API __attribute__((visibility("default")))
@@ -570,6 +570,57 @@ GRX_API int grx_comm_allgather(grx_comm* comm, const void* send, void* recv, siz
  */
 GRX_API int grx_group_normalize_tokenwise(const float* values, const float* mask, int32_t R, int32_t Tc, int32_t K,
                                   float eps, float* out, void* stream);
+
+/*
+ * Token-level prefix advantages: what TokenPrefixGRPOTrainer._generate_and_score_completions
+ * computes after generation (token_prefix_grpo_trainer.py:196-278) from the token-space
+ * reward builders (_build_prefix_token_rewards_with_error_mask, :107-149; the older
+ * _build_prefix_token_rewards, :65-105, yields the same token and sequence rewards) --
+ * there per-row Python loops with an .item() read-back per compared token.
+ *
+ * Row i's completion (completion_ids[i, :Tc], valid where completion_mask[i, p] > 0, a
+ * terminal eos_token_id ignored) is matched against gt_ids[i, :gt_len[i]], the token ids
+ * of its ground-truth text (:123): the matched prefix earns 1 / gt_len per token
+ * (normalize = 1) or 1, the row's sequence reward is their sum, valid positions behind
+ * the matched prefix form the error-token mask.  Then, for groups of K consecutive rows:
+ *   total_token_normalize = 1 (:209-246): raw token rewards
+ *       prefix_weight * prefix + ndcg_weight * ndcg_tok, ndcg_tok = 0 (has_ndcg = 0),
+ *       rank_weights[(i + rank_offset) % K] on the row's error tokens if any row of its
+ *       group has a positive sequence reward (error_token_penalty = 1; rank_weights are the
+ *       values of _build_ndcg_rank_penalties, :151-161, rank_offset = process_index * R),
+ *       or ndcg[i] on every valid token; normalised per (group, position) as
+ *       grx_group_normalize_tokenwise does.  Needs scratch [R, Tc].
+ *   total_token_normalize = 0 (:247-277): the sequence rewards normalised per group
+ *       (mean, unbiased std, eps) and spread over the matched tokens in proportion to their
+ *       token rewards, times prefix_weight; plus, with has_ndcg, ndcg_weight times the
+ *       group-normalised ndcg[i] on every valid token.
+ * The reference gathers the rewards of all ranks first and slices its own rows out again;
+ * groups never straddle ranks, so the local rows give the same values.  All pointers are
+ * device memory; completion_mask / outputs are fp32 [R, Tc] contiguous, seq_rewards [R];
+ * token_rewards, seq_rewards, error_mask may be null.
+ */
+typedef struct grx_token_prefix_args {
+    const int64_t* completion_ids;
+    int64_t ids_stride;
+    const float* completion_mask;
+    const int64_t* gt_ids;
+    int64_t gt_stride;
+    const int32_t* gt_len;
+    const float* ndcg;          /* [R] sequence-level NDCG rewards (ndcg_rule_reward) or null */
+    const float* rank_weights;  /* [K] or null                                               */
+    int32_t R, Tc, K;
+    int32_t eos_token_id;       /* -1: none                                                  */
+    int32_t normalize;          /* prefix_reward_normalize                                   */
+    int32_t total_token_normalize, has_ndcg, error_token_penalty;
+    int32_t rank_offset;
+    float prefix_weight, ndcg_weight, eps;
+    float* token_rewards;
+    float* seq_rewards;
+    float* error_mask;
+    float* scratch;
+    float* token_advantages;
+} grx_token_prefix_args;
+GRX_API int grx_token_prefix_advantages(const grx_token_prefix_args* args, void* stream);
 
 #ifdef __cplusplus
 }

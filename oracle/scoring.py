@@ -7,6 +7,8 @@ Restates:
   * sequence-level group advantage            -- fixed_hint_grpo_trainer.py:383-401
   * ``_group_normalize`` / ``_group_normalize_tokenwise`` / NDCG rank penalties
                                               -- token_prefix_grpo_trainer.py:41-63,151-161
+  * token-space prefix rewards, error-token mask and the token advantages composed from them
+                                              -- token_prefix_grpo_trainer.py:65-149,196-278
 """
 
 from __future__ import annotations
@@ -165,3 +167,77 @@ def ref_ndcg_rank_penalties(batch_size: int, num_generations: int, process_index
     w = -w / w.sum()  # token_prefix_grpo_trainer.py:151-161
     idx = (torch.arange(batch_size) + process_index * batch_size) % num_generations
     return w[idx]
+
+
+# ----------------------------------------------------------------- token-level prefix advantages ---
+def ref_prefix_token_rewards(completion_ids: torch.Tensor, completion_mask: torch.Tensor, gt_token_ids: list,
+                             eos_token_id: Optional[int], normalize: bool = True, with_error_mask: bool = True):
+    """(token_rewards [R, Tc], seq_rewards [R], error_token_mask [R, Tc] or None): the prefix match of every
+    completion against its ground truth IN TOKEN SPACE -- token_prefix_grpo_trainer.py:107-149
+    (``with_error_mask=False``: the older builder at :65-105, which differs only in skipping rows whose
+    ground truth is empty before anything else).  ``gt_token_ids[i]`` is what the tokenizer returns for row
+    i's ground-truth text (:123)."""
+    bsz, comp_len = completion_ids.shape
+    token_rewards = torch.zeros((bsz, comp_len), dtype=torch.float32)
+    seq_rewards = torch.zeros((bsz,), dtype=torch.float32)
+    error = torch.zeros((bsz, comp_len), dtype=torch.float32) if with_error_mask else None
+    for i in range(bsz):
+        gt = [int(t) for t in gt_token_ids[i]]
+        if not with_error_mask and len(gt) == 0:
+            continue
+        valid = [p for p in range(comp_len) if float(completion_mask[i, p]) > 0]
+        if not valid:
+            continue
+        ids = [int(completion_ids[i, p]) for p in valid]
+        if ids and eos_token_id is not None and ids[-1] == int(eos_token_id):  # terminal EOS takes no part
+            ids, valid = ids[:-1], valid[:-1]
+        if with_error_mask and not valid:
+            continue
+        matched = 0
+        while matched < min(len(ids), len(gt)) and ids[matched] == gt[matched]:
+            matched += 1
+        if len(gt) > 0 and matched > 0:
+            per_tok = 1.0 / float(len(gt)) if normalize else 1.0
+            for p in valid[:matched]:
+                token_rewards[i, p] = per_tok
+            seq_rewards[i] = float(matched) * float(per_tok)
+        if with_error_mask:
+            for p in valid[matched:]:
+                error[i, p] = 1.0
+    return token_rewards, seq_rewards, error
+
+
+def ref_token_prefix_advantages(prefix_token_rewards: torch.Tensor, prefix_seq: torch.Tensor,
+                                error_token_mask: torch.Tensor, completion_mask: torch.Tensor, num_generations: int,
+                                prefix_weight: float, ndcg_weight: float, has_ndcg: bool,
+                                ndcg_local: Optional[torch.Tensor], total_token_normalize: bool,
+                                error_token_penalty: bool, process_index: int = 0, gather=lambda t: t,
+                                n_local: Optional[int] = None) -> torch.Tensor:
+    """Token advantages of the token-level trainer -- token_prefix_grpo_trainer.py:201-278.  ``has_ndcg``: an
+    ``ndcg_rule_reward`` is among the reward functions (:163-172); ``ndcg_local`` is its output for the local
+    rows, needed where the reference calls it (:226-236, :263-273); ``gather`` stands for
+    ``accelerate.utils.gather`` (identity on one rank)."""
+    n_local = prefix_seq.shape[0] if n_local is None else n_local
+    mask = completion_mask.float()
+    sl = slice(process_index * n_local, (process_index + 1) * n_local)
+    K = num_generations
+    if total_token_normalize:
+        if not has_ndcg:
+            ndcg_tok = torch.zeros_like(prefix_token_rewards)  # :210-211
+        elif error_token_penalty:  # :212-223
+            positive = gather((prefix_seq > 0).float())
+            group_has = positive.view(-1, K).max(dim=1).values.repeat_interleave(K)[sl].unsqueeze(1)
+            rank = ref_ndcg_rank_penalties(n_local, K, process_index)
+            ndcg_tok = rank.unsqueeze(1) * error_token_mask * group_has
+        else:  # :224-237
+            ndcg_tok = ndcg_local.unsqueeze(1) * mask
+        total = prefix_weight * prefix_token_rewards + ndcg_weight * ndcg_tok  # :240
+        return ref_group_normalize_tokenwise(gather(total), gather(mask), K)[sl]  # :241-246
+    adv_prefix = ref_group_normalize(gather(prefix_seq), K)[sl]  # :249-251
+    mass = prefix_token_rewards.sum(dim=1, keepdim=True)
+    dist = torch.where(mass > 0, prefix_token_rewards / (mass + 1e-8), torch.zeros_like(prefix_token_rewards))
+    out = prefix_weight * adv_prefix.unsqueeze(1) * dist  # :255-261
+    if has_ndcg:  # :262-277
+        adv_ndcg = ref_group_normalize(gather(ndcg_local), K)[sl]
+        out = out + ndcg_weight * adv_ndcg.unsqueeze(1) * mask
+    return out

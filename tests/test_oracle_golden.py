@@ -7,7 +7,9 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import INDEX_NAMES, load_json_gz, load_npz, write_index_file
+import os
+
+from helpers import GOLDEN, INDEX_NAMES, load_json_gz, load_npz, write_index_file
 from oracle import beam as obeam
 from oracle import processors as oproc
 from oracle import scoring as oscore
@@ -329,3 +331,25 @@ def test_oracle_reproduces_evaluation_style_generate_with_50_beams_and_repetitio
         assert torch.equal(seqs_o[live], torch.from_numpy(data[f"{name}.sequences"])[live])
         assert torch.equal(bidx_o.long()[live], torch.from_numpy(data[f"{name}.beam_indices"]).long()[live])
         assert inner.count == batch["steps"]
+
+
+def test_token_prefix_oracle_bit_exact_with_the_reference_trainer():
+    """token_prefix.npz holds what the reference's TokenPrefixGRPOTrainer produced (reward builders and
+    _generate_and_score_completions, token_prefix_grpo_trainer.py:107-149,174-287): the restatement must
+    reproduce token rewards, sequence rewards, error masks and advantages bit for bit."""
+    d = np.load(os.path.join(GOLDEN, "token_prefix.npz"))
+    n, eos = int(d["n_cases"][0]), int(d["n_cases"][1])
+    assert n == 72
+    for c in range(n):
+        K, normalize, has_ndcg, total, err_pen = (int(v) for v in d[f"c{c}.cfg"])
+        pw, nw, _ = (float(v) for v in d[f"c{c}.weights"])
+        ids, mask = torch.from_numpy(d[f"c{c}.ids"]), torch.from_numpy(d[f"c{c}.mask"].astype(np.int64))
+        gt = [row[:n_].tolist() for row, n_ in zip(d[f"c{c}.gt_ids"], d[f"c{c}.gt_len"])]
+        tr, sr, em = oscore.ref_prefix_token_rewards(ids, mask, gt, eos, bool(normalize), True)
+        assert torch.equal(tr, torch.from_numpy(d[f"c{c}.token_rewards"]))
+        assert torch.equal(sr, torch.from_numpy(d[f"c{c}.seq_rewards"]))
+        assert torch.equal(em, torch.from_numpy(d[f"c{c}.error_mask"].astype(np.float32)))
+        ndcg = torch.from_numpy(d[f"c{c}.ndcg"]) if has_ndcg else None
+        adv = oscore.ref_token_prefix_advantages(tr, sr, em, mask, K, pw, nw, bool(has_ndcg), ndcg, bool(total),
+                                                 bool(err_pen))
+        assert torch.equal(adv, torch.from_numpy(d[f"c{c}.advantages"])), c
