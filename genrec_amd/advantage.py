@@ -139,6 +139,31 @@ class RolloutAdvantages:
             self._global = group_advantages(self.gathered_rewards_per_func(), w, K, scale, eps)
         return self._global
 
+    def logged_statistics(self, reward_func_names) -> dict:
+        """The scalars the reference logs after a rollout (fixed_hint_grpo_trainer.py:410-417):
+        ``rewards/<name>/mean`` and ``/std`` per reward function (nan-aware, unbiased -- TRL's ``nanstd``),
+        ``reward``, ``reward_std`` and ``frac_reward_zero_std`` over the rows of all ranks, as Python
+        floats -- computed on the device and fetched with ONE read-back where the reference issues
+        2 x n_funcs + 3 ``.item()`` calls."""
+        rpf = self.gathered_rewards_per_func().to(torch.float32)
+        _, _, mean, std = self.wait_global()
+        col_mean = torch.nanmean(rpf, dim=0)
+        present = ~torch.isnan(rpf)
+        count = present.sum(dim=0).to(torch.float32)
+        var = torch.nanmean((rpf - col_mean[None, :]) ** 2, dim=0) * (count / (count - 1))
+        zero_std = torch.isclose(std, torch.zeros_like(std)).float().mean()
+        packed = torch.cat([col_mean, torch.sqrt(var), torch.stack([mean.mean(), std.mean(), zero_std])]).tolist()
+        n = rpf.shape[1]
+        names = list(reward_func_names)
+        if len(names) != n:
+            raise ValueError(f"{len(names)} reward function names for {n} reward columns")
+        out = {}
+        for i, name in enumerate(names):
+            out[f"rewards/{name}/mean"] = packed[i]
+            out[f"rewards/{name}/std"] = packed[n + i]
+        out["reward"], out["reward_std"], out["frac_reward_zero_std"] = packed[2 * n], packed[2 * n + 1], packed[2 * n + 2]
+        return out
+
     def __iter__(self):  # (local_advantages, all_advantages, rewards, group_mean, std)
         rewards, adv, mean, std = self.wait_global()
         return iter((self.local_advantages, adv, rewards, mean, std))

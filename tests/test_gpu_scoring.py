@@ -320,3 +320,37 @@ def test_one_launch_scoring_equals_rewards_then_advantages(K, want):
     assert torch.equal(res.local_advantages, ref[1])
     with pytest.raises(ValueError):
         scorer.score_with_advantages(comp.to(dev), gt.to(dev), w, "batch", want=want)
+
+
+@pytest.mark.parametrize("scale", ["group", "batch", "none"])
+def test_logged_statistics_come_back_in_one_read(scale):
+    """fixed_hint_grpo_trainer.py:410-417 restated with the torch operations the reference uses (TRL's nanstd:
+    nan-aware mean of squared deviations, times count / (count - 1)), NaN rewards included."""
+    from genrec_amd.advantage import rollout_advantages
+
+    dev = _dev()
+    K, G = 8, 12
+    torch.manual_seed(4)
+    rpf = torch.randn(G * K, 3)
+    rpf[::7, 1] = float("nan")  # a reward function that returned None for some rows
+    rpf[K : 2 * K] = 0.25       # a group without spread
+    w = torch.tensor([1.0, 0.5, 2.0])
+    res = rollout_advantages(rpf.to(dev), w.to(dev), K, scale)
+    got = res.logged_statistics(["rule_reward", "prefix_rule_reward", "ndcg_rule_reward"])
+    rewards = (rpf * w.unsqueeze(0)).nansum(dim=1)
+    mean = rewards.view(-1, K).mean(dim=1).repeat_interleave(K)
+    std = rewards.std().expand_as(rewards) if scale == "batch" else rewards.view(-1, K).std(dim=1).repeat_interleave(K)
+    want = {"reward": mean.mean().item(), "reward_std": std.mean().item(),
+            "frac_reward_zero_std": torch.isclose(std, torch.zeros_like(std)).float().mean().item()}
+    for i, name in enumerate(["rule_reward", "prefix_rule_reward", "ndcg_rule_reward"]):
+        col = rpf[:, i]
+        want[f"rewards/{name}/mean"] = torch.nanmean(col).item()
+        var = torch.nanmean((col - torch.nanmean(col, keepdim=True)) ** 2)
+        n = torch.sum(~torch.isnan(col))
+        want[f"rewards/{name}/std"] = torch.sqrt(var * n / (n - 1)).item()
+    assert set(got) == set(want)
+    for k in want:
+        assert abs(got[k] - want[k]) <= 1e-5 * max(1.0, abs(want[k])), (k, got[k], want[k])
+    assert got["frac_reward_zero_std"] > 0 or scale == "batch"
+    with pytest.raises(ValueError):
+        res.logged_statistics(["only_one"])
