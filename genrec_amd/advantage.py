@@ -144,7 +144,9 @@ class RolloutAdvantages:
         ``rewards/<name>/mean`` and ``/std`` per reward function (nan-aware, unbiased -- TRL's ``nanstd``),
         ``reward``, ``reward_std`` and ``frac_reward_zero_std`` over the rows of all ranks, as Python
         floats -- computed on the device and fetched with ONE read-back where the reference issues
-        2 x n_funcs + 3 ``.item()`` calls."""
+        2 x n_funcs + 3 ``.item()`` calls.  ``nanstd`` lives in TRL (``trl.trainer.utils``), which is not
+        installed where this was written: its published formula (nan-aware mean of squared deviations
+        times count / (count - 1), square root) is restated here -- parity unpinned on that one function."""
         rpf = self.gathered_rewards_per_func().to(torch.float32)
         _, _, mean, std = self.wait_global()
         col_mean = torch.nanmean(rpf, dim=0)
