@@ -59,6 +59,17 @@ def rank_penalty_weights(num_generations: int) -> torch.Tensor:
     return -w / w.sum()
 
 
+_RANK_WEIGHTS: dict = {}
+
+
+def _rank_weights_on(num_generations: int, device) -> torch.Tensor:
+    key = (int(num_generations), str(device))
+    w = _RANK_WEIGHTS.get(key)
+    if w is None:
+        w = _RANK_WEIGHTS[key] = rank_penalty_weights(num_generations).to(device)
+    return w
+
+
 def token_prefix_advantages(
     completion_ids: torch.Tensor,
     completion_mask: torch.Tensor,
@@ -104,7 +115,7 @@ def token_prefix_advantages(
     if gt_ids.shape[0] != R or gt_len.shape[0] != R:
         raise ValueError("one ground truth per completion row")
     nd = ndcg_rewards.to(device=dev, dtype=torch.float32).contiguous() if (needs_ndcg and ndcg_rewards is not None) else None
-    rank = rank_penalty_weights(K).to(dev) if (has_ndcg and total and err_pen) else None
+    rank = _rank_weights_on(K, dev) if (has_ndcg and total and err_pen) else None
     out = TokenPrefixAdvantages(
         token_advantages=torch.empty((R, Tc), dtype=torch.float32, device=dev),
         token_rewards=torch.empty((R, Tc), dtype=torch.float32, device=dev),
