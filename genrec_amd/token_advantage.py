@@ -134,7 +134,7 @@ def token_prefix_advantages(
     a.eos_token_id = -1 if eos_token_id is None else int(eos_token_id)
     a.normalize = 1 if prefix_reward_normalize else 0
     a.total_token_normalize, a.has_ndcg, a.error_token_penalty = int(total), int(bool(has_ndcg)), int(err_pen)
-    a.rank_offset = int(process_index) * R
+    a.rank_offset = (int(process_index) * R) % K  # only its remainder enters the rank index (:159-160)
     a.prefix_weight, a.ndcg_weight, a.eps = float(prefix_weight), float(ndcg_weight if has_ndcg else 0.0), float(eps)
     a.token_rewards, a.seq_rewards = out.token_rewards.data_ptr(), out.seq_rewards.data_ptr()
     a.error_mask = out.error_token_mask.data_ptr()
