@@ -55,7 +55,8 @@ def build_workload(args, device):
     fn = create_prefix_allowed_tokens_fn(trie, suffix)
     V = tok.vocab_size_padded
     cls = FixedHintConstrainedLogitsProcessor if args.processor == "fixed_hint" else ConstrainedLogitsProcessor
-    proc = cls(fn, args.beams, pidx, suffix, tok.eos_token_id)
+    extras = {"repetition_penalty": args.repetition_penalty} if args.repetition_penalty != 1.0 else {}
+    proc = cls(fn, args.beams, pidx, suffix, tok.eos_token_id, **extras)
     levels = len(trie.level_fanout()) - len(suffix)  # SID levels + EOS
     rank = int(os.environ.get("RANK", "0"))
     prompts = sample_decode_rows(trie, args.batch, 1, 0, prompt_len=args.prompt_len, seed=1000 + rank)
@@ -388,6 +389,8 @@ def main() -> None:
                     help="Industrial_and_Scientific | Instruments | Games | Arts | cb<codebook size> (synthetic)")
     ap.add_argument("--processor", default="count", choices=["count", "fixed_hint"])
     ap.add_argument("--prompt-len", type=int, default=61)
+    ap.add_argument("--repetition-penalty", type=float, default=1.0,
+                    help="fold transformers' repetition penalty over the whole row into the step (evaluate.py:218 uses 1.1)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--cpu-groups", type=int, default=0,
                     help="prompt groups of the CPU baseline sample (0: all of --batch, i.e. the real row count)")

@@ -132,7 +132,7 @@ __device__ __forceinline__ void select_top(const uint32_t* s_key, const float* s
 // DT: element type of the logits.  OUT: OUT_*.  VEC: rows (and, for the full
 // modes, output rows) are 16-byte aligned so the stream uses 16-byte accesses;
 // otherwise one element per access.
-template <int DT, int OUT, bool VEC, bool SPLIT>
+template <int DT, int OUT, bool VEC, bool SPLIT, bool PEN>
 __global__ __launch_bounds__(MLS_THREADS) void masked_lsm_kernel(MlsArgs a) {
     typedef Elem<DT> E;
     typedef typename E::T T;
@@ -223,6 +223,44 @@ __global__ __launch_bounds__(MLS_THREADS) void masked_lsm_kernel(MlsArgs a) {
         }
     };
     if (!SPLIT) gather();
+
+    // Repetition penalty: the distinct tokens of ids[r, pen_from:T) go into an LDS set, and the thread
+    // that put a token there first fetches its raw logit -- all of it now, ahead of the stream, so the
+    // scattered reads (a few hundred per row, anywhere in the row) are in flight together with the
+    // stream's loads instead of standing between the row's log-sum-exp and its output.
+    __shared__ int s_pen[PEN_SLOTS];
+    __shared__ float s_pen_red[2][MLS_WAVES];
+    constexpr bool pen_on = PEN;  // a.penalty > 0: its own instantiation, so the others carry none of this
+    constexpr int PEN_PER_THREAD = GRX_MAX_PENALTY_TOKENS / MLS_THREADS;
+    static_assert(PEN_PER_THREAD * MLS_THREADS == GRX_MAX_PENALTY_TOKENS, "penalty tokens per thread");
+    float p_raw[PEN_PER_THREAD];
+    unsigned p_first = 0;  // bit k: this thread entered its k-th token into the set (first occurrence)
+    auto pen_collect = [&]() {
+        for (int i = tid; i < PEN_SLOTS; i += MLS_THREADS) s_pen[i] = -1;
+        __syncthreads();
+        const int64_t* __restrict__ ids_row = a.ids + (int64_t)r * a.ids_stride;
+#pragma unroll
+        for (int k = 0; k < PEN_PER_THREAD; ++k) {
+            const int t = a.pen_from + tid + k * MLS_THREADS;
+            p_raw[k] = 0.f;
+            if (t >= a.T) continue;
+            const int64_t tk = ids_row[t];
+            if (tk < 0 || tk >= (int64_t)a.V) continue;
+            const int tokv = (int)tk;
+            uint32_t h = ((uint32_t)tokv * 0x9E3779B1u) >> (32 - PEN_SLOT_BITS);
+            for (;;) {
+                const int old = atomicCAS(&s_pen[h], -1, tokv);
+                if (old == -1) {
+                    p_first |= 1u << k;
+                    p_raw[k] = E::to_float(row[tokv]);
+                    break;
+                }
+                if (old == tokv) break;
+                h = (h + 1) & (PEN_SLOTS - 1);
+            }
+        }
+    };
+    if (pen_on && !SPLIT) pen_collect();
 
     MSTAMP(2);
     // Stream the row once.
@@ -366,9 +404,6 @@ __global__ __launch_bounds__(MLS_THREADS) void masked_lsm_kernel(MlsArgs a) {
     //   sum_v exp(y'_v) = (S - sum_U exp(x_v - m)) / S + sum_U exp(y'_v),  U = distinct ids.
     // Both terms are O(1) or smaller and the total is >= ~0.5, so the subtraction
     // costs no accuracy that matters at fp32.
-    __shared__ int s_pen[PEN_SLOTS];
-    __shared__ float s_pen_red[2][MLS_WAVES];
-    const bool pen_on = a.penalty > 0.f;
     float lse2 = 0.f;
     auto penalised = [&](float y) { return y < 0.f ? y * a.penalty : y / a.penalty; };
     auto in_pen_set = [&](int tokv) {
@@ -381,24 +416,12 @@ __global__ __launch_bounds__(MLS_THREADS) void masked_lsm_kernel(MlsArgs a) {
         }
     };
     if (pen_on) {
-        for (int i = tid; i < PEN_SLOTS; i += MLS_THREADS) s_pen[i] = -1;
-        __syncthreads();
-        const int64_t* __restrict__ ids_row = a.ids + (int64_t)r * a.ids_stride;
+        if (SPLIT) pen_collect();  // the emitting workgroup of a split row collects now
         float sub = 0.f, add = 0.f;
-        for (int t = a.pen_from + tid; t < a.T; t += MLS_THREADS) {
-            const int64_t tk = ids_row[t];
-            if (tk < 0 || tk >= (int64_t)a.V) continue;
-            const int tokv = (int)tk;
-            uint32_t h = ((uint32_t)tokv * 0x9E3779B1u) >> (32 - PEN_SLOT_BITS);
-            bool first = false;
-            for (;;) {
-                const int old = atomicCAS(&s_pen[h], -1, tokv);
-                if (old == -1) { first = true; break; }
-                if (old == tokv) break;
-                h = (h + 1) & (PEN_SLOTS - 1);
-            }
-            if (first) {
-                const float xm = E::to_float(row[tokv]) - tot.m;
+#pragma unroll
+        for (int k = 0; k < PEN_PER_THREAD; ++k) {
+            if (p_first & (1u << k)) {
+                const float xm = p_raw[k] - tot.m;
                 sub += fast_exp2(xm * kLog2e);
                 add += fast_exp2(penalised(xm - log_s) * kLog2e);
             }
@@ -704,15 +727,21 @@ static void launch_one(KernelT kernel, const MlsArgs& a, hipStream_t stream, hip
         hipLaunchKernelGGL(kernel, grid, dim3(MLS_THREADS), 0, stream, a);
 }
 
+template <int DT, int OUT, bool VEC, bool SPLIT>
+static void launch_pen(const MlsArgs& a, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
+    if (a.penalty > 0.f) launch_one(masked_lsm_kernel<DT, OUT, VEC, SPLIT, true>, a, stream, ev0, ev1);
+    else launch_one(masked_lsm_kernel<DT, OUT, VEC, SPLIT, false>, a, stream, ev0, ev1);
+}
+
 template <int DT, int OUT, bool VEC>
 static void launch_split(const MlsArgs& a, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
     if constexpr (VEC) {  // only 16-byte streams are split
         if (a.S > 1) {
-            launch_one(masked_lsm_kernel<DT, OUT, VEC, true>, a, stream, ev0, ev1);
+            launch_pen<DT, OUT, VEC, true>(a, stream, ev0, ev1);
             return;
         }
     }
-    launch_one(masked_lsm_kernel<DT, OUT, VEC, false>, a, stream, ev0, ev1);
+    launch_pen<DT, OUT, VEC, false>(a, stream, ev0, ev1);
 }
 
 template <int DT, int OUT>
