@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Time grx_beam_step of build variants (genrec_amd/variants/lib_*.so) on synthetic candidates.
+"""Time grx_beam_step of build variants (build/variants/lib_*.so) on synthetic candidates.
 Shape from the environment: AB_B groups, AB_K beams, AB_CMAX row width, AB_FANS comma-separated fan-outs."""
 import ctypes as C
 import glob
@@ -20,7 +20,7 @@ def main():
     fans = [int(x) for x in os.environ.get('AB_FANS', '162,43,2').split(',')]
     R = B * K
     prompts = torch.randint(5, 90, (R, 64), device=dev)
-    names = sys.argv[1:] or sorted(os.path.basename(p)[4:-3] for p in glob.glob(os.path.join(ROOT, "genrec_amd/variants/lib_*.so")))
+    names = sys.argv[1:] or sorted(os.path.basename(p)[4:-3] for p in glob.glob(os.path.join(ROOT, "build/variants/lib_*.so")))
     for fan in fans:
         cnt = torch.full((R,), fan, dtype=torch.int32, device=dev)
         tok = (torch.arange(cmax, device=dev, dtype=torch.int32)[None, :] * 3 + 151665).repeat(R, 1).contiguous()
@@ -28,7 +28,7 @@ def main():
         from genrec_amd.logit_processor import Candidates
         cand = Candidates.from_parts(cnt, tok, lp, dev)
         for name in names:
-            h = C.CDLL(os.path.join(ROOT, "genrec_amd/variants", f"lib_{name}.so"))
+            h = C.CDLL(os.path.join(ROOT, "build/variants", f"lib_{name}.so"))
             _lib._declare(h)
             real = _lib._lib
             _lib._lib = h
