@@ -19,6 +19,10 @@
 
 enum { OUT_COMPACT = 0, OUT_FULL_F32 = 1, OUT_FULL_SAME = 2 };
 
+#ifndef MLS_HEAD_BATCHES
+#define MLS_HEAD_BATCHES 4  // batches of MLS_UNROLL loads per thread that may be issued before a row's trie node is looked up
+#endif
+
 struct MlsArgs {
     const int32_t* tok;    // child tokens of the trie (CSR)
     const int32_t* off;    // child offsets of the trie (CSR)
@@ -56,6 +60,7 @@ struct MlsArgs {
     // else already, so instead of a fill pass the kernel resets just those positions.
     grx_row_plan* last;
     int prefilled;
+    int head_batches;      // opening batches of loads per thread (<= MLS_HEAD_BATCHES)
 };
 
 
@@ -153,8 +158,8 @@ __global__ __launch_bounds__(MLS_THREADS) void masked_lsm_kernel(MlsArgs a) {
     if (a.R < 0 && s_pad[(tid * 7) % (MLS_LDS_PAD / 4)] == 3) return;
 #endif
 
-    // The first batch of the stream is issued before anything else: the plan
-    // lookup below is a scalar load, which does not queue behind it.
+    // The opening batches of the stream are issued before anything else: the node
+    // look-up below runs on scalar loads, which do not queue behind them.
     const int nvec = a.V / EPV;
     int v_lo = 0, v_hi = nvec;  // this workgroup's share of the row's vectors
     if (SPLIT) {
@@ -163,11 +168,20 @@ __global__ __launch_bounds__(MLS_THREADS) void masked_lsm_kernel(MlsArgs a) {
         v_hi = v_lo + per < nvec ? v_lo + per : nvec;
     }
     const RowStream vp(row, (int64_t)nvec * 16);
-    u32x4 v_head[MLS_UNROLL];
-    const bool head = VEC && !a.skip_stream && (v_lo + tid + (MLS_UNROLL - 1) * MLS_THREADS < v_hi);
-    if (head) {
+    // The opening batches: 64 KB of the row per workgroup are in flight while the node look-up below waits
+    // for its dependent scalar loads (about 10 us under load).  With one batch the memory system ran dry
+    // behind every look-up -- all of them at once when a launch starts: 370.2 -> 366.5 us per launch.
+    constexpr int HEADN = MLS_UNROLL * MLS_HEAD_BATCHES;
+    u32x4 v_head[HEADN];
+    const int n_full = (v_hi - v_lo) / (MLS_UNROLL * MLS_THREADS);  // batches in which every thread takes part
+    const int hbn = (VEC && !a.skip_stream) ? (n_full < a.head_batches ? n_full : a.head_batches) : 0;
 #pragma unroll
-        for (int u = 0; u < MLS_UNROLL; ++u) v_head[u] = vp.load(v_lo + tid + u * MLS_THREADS);
+    for (int hb = 0; hb < MLS_HEAD_BATCHES; ++hb) {
+        if (hb < hbn) {
+#pragma unroll
+            for (int u = 0; u < MLS_UNROLL; ++u)
+                v_head[hb * MLS_UNROLL + u] = vp.load(v_lo + tid + (hb * MLS_UNROLL + u) * MLS_THREADS);
+        }
     }
 
     // Which trie node governs this row.  Count-based mode: walked here -- every operand is uniform
@@ -281,9 +295,12 @@ __global__ __launch_bounds__(MLS_THREADS) void masked_lsm_kernel(MlsArgs a) {
         };
 
         int i = v_lo + tid;
-        if (head) {
-            consume(v_head, i);
-            i += MLS_UNROLL * MLS_THREADS;
+#pragma unroll
+        for (int hb = 0; hb < MLS_HEAD_BATCHES; ++hb) {
+            if (hb < hbn) {
+                consume(v_head + hb * MLS_UNROLL, i);
+                i += MLS_UNROLL * MLS_THREADS;
+            }
         }
         for (; i + (MLS_UNROLL - 1) * MLS_THREADS < v_hi; i += MLS_UNROLL * MLS_THREADS) {
             u32x4 v[MLS_UNROLL];
@@ -826,6 +843,9 @@ static int run_step(const char* who, const grx_trie* trie, grx_state* state, con
             a.split_part = reinterpret_cast<float2*>(reinterpret_cast<char*>(workspace) + GRX_SPLIT_COUNT_BYTES);
         }
     }
+    // launches of several rounds of workgroups open every row with the deep prefetch; a launch that fits the GPU
+    // in one round (few rows) gains nothing from it and its look-ups queue behind the extra loads
+    a.head_batches = (int64_t)a.R * a.S >= 2048 ? MLS_HEAD_BATCHES : 1;
     const int slot = timing_slot();
     hipEvent_t ev0 = slot >= 0 ? g_ev_start[slot] : nullptr, ev1 = slot >= 0 ? g_ev_stop[slot] : nullptr;
     if (out_kind != OUT_COMPACT && vec && !a.prefilled) {

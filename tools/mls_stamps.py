@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Phase timestamps inside the streaming kernel (needs a -DMLS_STAMP build at genrec_amd/variants/lib_stamp.so)."""
+"""Phase timestamps inside the streaming kernel (needs a -DMLS_STAMP build at build/variants/lib_stamp.so)."""
 import ctypes as C
 import os
 import sys
@@ -13,7 +13,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from genrec_amd import _lib  # noqa: E402
 
-_lib.LIB_PATH = os.path.join(ROOT, "genrec_amd/variants/lib_stamp.so")
+_lib.LIB_PATH = os.path.join(ROOT, "build/variants/lib_stamp.so")
 from genrec_amd.logit_processor import Candidates, ConstrainedLogitsProcessor  # noqa: E402
 from genrec_amd.synth import ASSISTANT_PREFIX, SidTokenizer, sample_decode_rows  # noqa: E402
 from genrec_amd.trie import build_trie_from_index, create_prefix_allowed_tokens_fn  # noqa: E402
@@ -52,3 +52,14 @@ for R in [int(x) for x in os.environ.get("ST_ROWS", "16,256,8192").split(",")]:
         d = d[st[:, i + 1] > 0]
         if len(d):
             print(f"   {nm:28s} median {np.median(d):7.2f} us   p90 {np.percentile(d, 90):7.2f}   max {d.max():7.2f}  (n={len(d)})")
+
+    if os.environ.get("ST_TIMELINE") and R >= 4096:
+        # how many of the stamped workgroups are streaming / between rows in every 4 us of the kernel
+        bins = np.arange(0, (st[:, 6].max() - t0) / 100.0 + 4, 4.0)
+        s_lo, s_hi = (st[:, 2] - t0) / 100.0, (st[:, 3] - t0) / 100.0
+        b_lo, b_hi = (st[:, 0] - t0) / 100.0, (st[:, 6] - t0) / 100.0
+        starts = np.histogram(b_lo, bins)[0]
+        print("   t(us)  starts  streaming  resident(stamped)")
+        for i in range(len(bins) - 1):
+            mid = bins[i] + 2.0
+            print(f"   {bins[i]:5.0f}  {starts[i]:6d}  {int(((s_lo <= mid) & (s_hi > mid)).sum()):9d}  {int(((b_lo <= mid) & (b_hi > mid)).sum()):8d}")
