@@ -13,7 +13,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from genrec_amd import _lib  # noqa: E402
 
-_lib.LIB_PATH = os.path.join(ROOT, "build/variants/lib_stamp.so")
+_lib.LIB_PATH = os.path.join(ROOT, "build/variants", os.environ.get("ST_LIB", "lib_stamp.so"))
 from genrec_amd.logit_processor import Candidates, ConstrainedLogitsProcessor  # noqa: E402
 from genrec_amd.synth import ASSISTANT_PREFIX, SidTokenizer, sample_decode_rows  # noqa: E402
 from genrec_amd.trie import build_trie_from_index, create_prefix_allowed_tokens_fn  # noqa: E402
