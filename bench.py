@@ -300,8 +300,8 @@ def settle(wl, device, patience_s=10.0, cap_s=45.0):
     After a process that held a lot of HBM exits (a test suite, a previous benchmark) the driver goes on
     working on the released memory for seconds, and whatever runs meanwhile reads 3-4 % slower
     (`tools/churn.py memory` followed by `tools/settle_probe.py` shows the step back up after ~6 s).
-    The read probe is sampled twice a second until four samples in a row reach the rate of an idle part, or
-    it has not improved by 0.5 % for `patience_s`, or `cap_s` have passed.  What was seen goes into the result line.
+    The read probe is sampled twice a second until four samples in a row reach the rate of an idle part and have
+    stopped climbing, or it has not improved by 0.5 % for `patience_s`, or `cap_s` have passed.  What was seen goes into the result line.
     """
     x = wl["logits"][min(1, len(wl["logits"]) - 1)]
     if x.numel() * x.element_size() < (1 << 30):
@@ -309,14 +309,22 @@ def settle(wl, device, patience_s=10.0, cap_s=45.0):
     t0 = time.perf_counter()
     first = best = last = time_read_probe(wl, device, launches=6)["GBps"]
     best_at = 0.0
-    in_a_row = 1 if first >= SETTLED_GBPS else 0
-    while in_a_row < 4:  # four samples in a row at the idle rate: the background work comes in bursts
+    seen = [first]
+
+    def settled():
+        # four samples in a row at the idle rate (the background work comes in bursts) that are no longer
+        # climbing: their mean within 0.3 % of the four before them
+        if len(seen) < 8 or min(seen[-4:]) < SETTLED_GBPS:
+            return False
+        return sum(seen[-4:]) <= 1.003 * sum(seen[-8:-4])
+
+    while not settled():
         now = time.perf_counter() - t0
         if (last < SETTLED_GBPS and now - best_at > patience_s) or now > cap_s:
             break
         time.sleep(0.5)
         last = time_read_probe(wl, device, launches=6)["GBps"]
-        in_a_row = in_a_row + 1 if last >= SETTLED_GBPS else 0
+        seen.append(last)
         if last > best * 1.005:
             best, best_at = last, time.perf_counter() - t0
     return {"waited_s": round(time.perf_counter() - t0, 2), "probe_GBps_first": round(first, 1),
