@@ -104,6 +104,7 @@ class Rollout:
         self.depth = 0
         self.exchange = None
         self.plan_ahead = not getattr(args, "no_plan_ahead", False)
+        self.lazy_turnover = bool(getattr(args, "lazy_turnover", False))
         self.prompt_rows = wl["prompts"].repeat_interleave(args.beams, dim=0).contiguous()
 
     def new_generation(self):
@@ -123,9 +124,10 @@ class Rollout:
 
     def step(self):
         wl = self.wl
-        if self.state is None or self.depth == wl["levels"]:
-            if self.state is not None:
-                self.score()
+        if self.state is None:
+            self.new_generation()
+        elif self.depth == wl["levels"] and self.lazy_turnover:
+            self.score()
             self.new_generation()
         flat = self.state.flat_running_sequences()
         wl["proc"].candidates_into(flat, wl["logits"][self.depth], self.cand, keep_top=self.keep,
@@ -134,6 +136,13 @@ class Rollout:
         planner = wl["proc"] if (self.plan_ahead and self.depth + 1 < wl["levels"]) else None
         self.state.step(self.cand, wl["V"], planner)
         self.depth += 1
+        if self.depth == wl["levels"] and not self.lazy_turnover:
+            # the generation is complete: its last step scores it and re-initialises the beam state from the
+            # prompts for the next one.  One scoring and one initialisation per rollout either way; done here,
+            # the host issues them while it is far ahead of the GPU, instead of as the first thing after a
+            # synchronisation, with the GPU waiting for the launches
+            self.score()
+            self.new_generation()
 
     def score(self):
         from genrec_amd.advantage import rollout_score
@@ -408,7 +417,12 @@ def main() -> None:
                     help="let every processor call run its own row planning kernel (as under the plain HF loop)")
     ap.add_argument("--no-keep-top", action="store_true",
                     help="rows emit every allowed token instead of their 2 x beams best (A/B of the row truncation)")
+    ap.add_argument("--lazy-turnover", action="store_true",
+                    help="score a finished generation and re-initialise the beam state at the start of the next "
+                         "generation's first step instead of at the end of its own last step (A/B)")
     ap.add_argument("--cand-width", type=int, default=0, help="candidate entries per row, at least (tuning)")
+    ap.add_argument("--ramp-steps", type=int, default=100,
+                    help="untimed steps that precede the timed region at least (the --warmup steps count towards them)")
     ap.add_argument("--no-settle", action="store_true",
                     help="start timing at once instead of first waiting for the GPU's read rate to recover from "
                          "whatever released memory before this process")
@@ -481,9 +495,13 @@ def main() -> None:
     # ... then, if this GPU is still busy with memory that other processes released, wait for it; the
     # warm-up steps come after the wait, so the timed region follows work, not sleep
     settled = None if args.no_settle else settle(wl, device)
-    for _ in range(args.warmup):
+    # ... and bring GPU and host up to speed: the wait above sleeps between its samples, and a region that
+    # follows a few milliseconds of work runs ~2 % slower than one that follows 40 ms of it (clocks on both
+    # sides of the bus).  At least `--ramp-steps` steps run here, in whole rollouts, ahead of the W warm-up steps.
+    ramp = -(-max(0, args.ramp_steps - args.warmup) // wl["levels"]) * wl["levels"]
+    for _ in range(ramp + args.warmup):
         roll.step()
-    roll.depth = wl["levels"]  # the timed region starts with a fresh generation
+    assert roll.depth == (wl["levels"] if roll.lazy_turnover else 0)  # the timed region starts with a fresh generation
     torch.cuda.synchronize()
     barrier()
     lib = _lib.lib()
@@ -557,6 +575,7 @@ def main() -> None:
                 # the same rows read by a kernel that only loads them (same access pattern): what the part offers
                 "read_probe": probe,
                 "settle": settled,
+                "untimed_steps_before_region": ramp + args.warmup,
                 "frac_of_read_probe": achieved / probe["GBps"] if probe["GBps"] else None,
             },
         }

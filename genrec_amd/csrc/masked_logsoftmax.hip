@@ -675,7 +675,8 @@ extern "C" int grx_timing_read(double* total_ms, int32_t* launches) {
 
 static int timing_slot() {
     if (g_timing_every == 0) return -1;
-    if ((g_timing_calls++ % g_timing_every) != 0 || g_timing_n >= TIMING_SLOTS) return -1;
+    // the every-th, 2 x every-th, ... call: not the first one, whose launch the host has not run ahead of yet
+    if ((g_timing_calls++ % g_timing_every) != g_timing_every - 1 || g_timing_n >= TIMING_SLOTS) return -1;
     while (g_ev_created <= g_timing_n) {
         if (hipEventCreate(&g_ev_start[g_ev_created]) != hipSuccess) return -1;
         if (hipEventCreate(&g_ev_stop[g_ev_created]) != hipSuccess) return -1;

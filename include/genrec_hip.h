@@ -316,8 +316,8 @@ GRX_API int grx_constrained_finish_penalised(const grx_rows* rows, const grx_con
 
 /*
  * Kernel timing for benchmarks (no counterpart in the reference).  While
- * enabled with every = k > 0, every k-th of the two calls above (the first
- * one after the enable included) attaches HIP events to the dispatch of its
+ * enabled with every = k > 0, every k-th of the two calls above (the k-th,
+ * 2k-th, ... after the enable) attaches HIP events to the dispatch of its
  * streaming kernel (compact form) or to the fill kernel's start and the
  * streaming kernel's end (dense form), up to 4096 timed calls per enable; the
  * row planning kernel is not included.  An event pair costs about 5 us of
