@@ -2,6 +2,7 @@
 """Benchmark of the trie-constrained decode step on MI355X.
 
     python bench.py --gpus 1 --steps 100 --warmup 20
+    python bench.py --gpus N ...      (starts the N ranks itself, one per GPU, and relays rank 0's line)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -394,6 +395,41 @@ def recorded_traffic(args, alg_bytes):
 
 
 
+def launch_ranks(n: int) -> int:
+    """Start `n` ranks of this script, one per GPU, the way the reference's launchers start theirs
+    (trl_trainer.sh:359-364 `accelerate launch --num_processes N`; evaluate.sh:140-152 one process per GPU),
+    relay rank 0's JSON line and return the exit status: non-zero when the ranks fail or print no line.
+
+    Runs before anything in this process has initialised the GPU; the ranks are a child process.
+    """
+    import socket
+    import subprocess
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    child = subprocess.Popen(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, text=True)
+    lines = 0
+    for ln in child.stdout:
+        if ln.startswith("{"):
+            lines += 1
+        sys.stdout.write(ln)
+        sys.stdout.flush()
+    rc = child.wait()
+    if rc != 0:
+        print(f"bench.py: the {n}-rank run exited with status {rc}", file=sys.stderr)
+        return rc if 0 < rc < 256 else 1
+    if lines != 1:
+        print(f"bench.py: the {n}-rank run printed {lines} result lines instead of one", file=sys.stderr)
+        return 1
+    return 0
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -433,12 +469,21 @@ def main() -> None:
                          "every depth is sampled equally)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: this process becomes the launcher.  Nothing here has touched the
+        # GPU (torch is not even imported yet), and the ranks are started as a child, never by replacing
+        # this process.
+        raise SystemExit(launch_ranks(args.gpus))
+
     import torch
     import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; "
+                         f"a line labelled {args.gpus} GPUs must come from {args.gpus} ranks")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; no HIP device is visible")
     # GENREC_BENCH_BACKEND=gloo rehearses the multi-rank flow with several ranks on one GPU
@@ -461,6 +506,14 @@ def main() -> None:
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(backend)
+
+    # who is really here: every rank reports the device it runs on, and the line carries the count
+    seen = [(rank, torch.cuda.current_device(), torch.cuda.get_device_name(device))]
+    if dist_on:
+        seen = [None] * world
+        dist.all_gather_object(seen, (rank, torch.cuda.current_device(), torch.cuda.get_device_name(device)))
+    if len({r for r, _, _ in seen}) != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but {len(seen)} ranks answered")
 
     from genrec_amd import _lib
 
@@ -539,6 +592,8 @@ def main() -> None:
             "value": world * args.steps / elapsed,
             "unit": "steps/s",
             "n_gpus": world,
+            "ranks_seen": len(seen),
+            "devices": [f"rank {r}: cuda:{d} {name}" for r, d, name in sorted(seen)],
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
@@ -566,6 +621,8 @@ def main() -> None:
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
+                # the same bytes over the whole step (everything `value` pays for), slowest rank
+                "step_frac": alg_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
                 "traffic": traffic,
                 "traffic_source": traffic_source,
                 "algorithmic_bytes_per_launch": alg_bytes,

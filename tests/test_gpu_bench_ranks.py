@@ -50,3 +50,33 @@ def test_bench_through_rccl_with_one_rank():
         assert len(lines) == 1
         d = json.loads(lines[0])
         assert d["n_gpus"] == 1 and d["value"] > 0 and d["roofline"]["launches_timed"] >= 2
+
+
+@pytest.mark.gpu
+def test_plain_invocation_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it starts two ranks itself (the reference's
+    launchers do the same: trl_trainer.sh:359-364, evaluate.sh:140-152) and says in the line who answered."""
+    env = dict(os.environ, GENREC_BENCH_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "32", "--steps", "10",
+           "--warmup", "5"]
+    run = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=280)
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-4000:]
+    lines = [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and len(d["devices"]) == 2
+    assert d["roofline"]["step_frac"] > 0
+
+
+@pytest.mark.gpu
+def test_rank_count_that_contradicts_the_flag_is_refused():
+    """A launcher that started one rank cannot produce a line labelled two GPUs."""
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29641")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "32", "--steps", "5",
+           "--warmup", "5", "--no-cpu-baseline", "--no-processor-surface"]
+    run = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=120)
+    assert run.returncode != 0
+    assert not [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
+    assert "WORLD_SIZE=1" in run.stderr

@@ -348,3 +348,20 @@ def test_entry_points_reject_bad_arguments_on_the_host():
     assert lib.grx_hit_ranks(None, None, 0, 4, 4, None, None, None) == 0
     a.B, a.V = 0, 100
     assert lib.grx_beam_step(C.byref(a), None) == 0
+
+
+def test_bench_launcher_reports_failed_ranks():
+    """`bench.py --gpus 2` without a launcher starts its ranks as a child process; when they fail (here:
+    no GPU) the launcher prints no result line and exits non-zero instead of labelling one rank's run."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["HIP_VISIBLE_DEVICES"] = ""
+    env["CUDA_VISIBLE_DEVICES"] = ""
+    run = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--batch", "32", "--steps", "5"],
+                         env=env, cwd=root, capture_output=True, text=True, timeout=120)
+    assert run.returncode != 0
+    assert not [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
+    assert "2-rank run exited" in run.stderr
