@@ -161,16 +161,35 @@ __device__ __forceinline__ int py_tail_start(int k, int T) {
     return s < T ? s : T;
 }
 
+// Wave-wide reductions on the data-parallel-primitive path of the vector ALU: four row shifts fold
+// each row of 16 lanes into its last lane, two row broadcasts fold the four rows into lane 63, whose
+// value is read back as a scalar.  Six dependent ALU operations instead of six LDS permutes (a
+// shuffle costs an LDS round trip each, and these sit at the very end of a workgroup's life, when its
+// slot issues no loads).  Every lane must be active.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_take(float ident, float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(ident), __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+}
+
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, GRX_WAVE));
-    return v;
+    const float ninf = -__builtin_inff();
+    v = fmaxf(v, dpp_take<0x111, 0xF>(ninf, v));  // row_shr:1
+    v = fmaxf(v, dpp_take<0x112, 0xF>(ninf, v));  // row_shr:2
+    v = fmaxf(v, dpp_take<0x114, 0xF>(ninf, v));  // row_shr:4
+    v = fmaxf(v, dpp_take<0x118, 0xF>(ninf, v));  // row_shr:8
+    v = fmaxf(v, dpp_take<0x142, 0xA>(ninf, v));  // row_bcast:15 into rows 1 and 3
+    v = fmaxf(v, dpp_take<0x143, 0xC>(ninf, v));  // row_bcast:31 into rows 2 and 3
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, GRX_WAVE);
-    return v;
+    v += dpp_take<0x111, 0xF>(0.f, v);
+    v += dpp_take<0x112, 0xF>(0.f, v);
+    v += dpp_take<0x114, 0xF>(0.f, v);
+    v += dpp_take<0x118, 0xF>(0.f, v);
+    v += dpp_take<0x142, 0xA>(0.f, v);
+    v += dpp_take<0x143, 0xC>(0.f, v);
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {

@@ -100,6 +100,10 @@ template <> struct Elem<GRX_F32> {
         f[2] = __uint_as_float(v.z); f[3] = __uint_as_float(v.w);
     }
     static __device__ __forceinline__ float from_float(float v) { return v; }
+    // element k of a loaded vector, k not known at compile time
+    static __device__ __forceinline__ float element(const u32x4& v, int k) {
+        return __uint_as_float(k < 2 ? (k == 0 ? v.x : v.y) : (k == 2 ? v.z : v.w));
+    }
     static constexpr uint32_t kNegInfPacked = 0xFF800000u;
 };
 template <> struct Elem<GRX_BF16> {
@@ -115,6 +119,10 @@ template <> struct Elem<GRX_BF16> {
     static __device__ __forceinline__ uint16_t from_float(float v) {
         __hip_bfloat16 b = __float2bfloat16(v);
         return *reinterpret_cast<uint16_t*>(&b);
+    }
+    static __device__ __forceinline__ float element(const u32x4& v, int k) {
+        const uint32_t w = k < 4 ? (k < 2 ? v.x : v.y) : (k < 6 ? v.z : v.w);
+        return __uint_as_float((k & 1) ? (w & 0xFFFF0000u) : (w << 16));
     }
     static constexpr uint32_t kNegInfPacked = 0xFF80FF80u;
 };
@@ -136,6 +144,10 @@ template <> struct Elem<GRX_F16> {
     static __device__ __forceinline__ uint16_t from_float(float v) {
         __half h = __float2half(v);
         return *reinterpret_cast<uint16_t*>(&h);
+    }
+    static __device__ __forceinline__ float element(const u32x4& v, int k) {
+        const uint32_t w = k < 4 ? (k < 2 ? v.x : v.y) : (k < 6 ? v.z : v.w);
+        return to_float((uint16_t)((k & 1) ? (w >> 16) : (w & 0xFFFFu)));
     }
     static constexpr uint32_t kNegInfPacked = 0xFC00FC00u;
 };

@@ -19,6 +19,9 @@
 
 enum { OUT_COMPACT = 0, OUT_FULL_F32 = 1, OUT_FULL_SAME = 2 };
 
+#ifndef PEN_STASH
+#define PEN_STASH 4  // 16-byte LDS slots per thread for vectors that hold penalised tokens (repetition penalty)
+#endif
 #ifndef MLS_HEAD_BATCHES
 #define MLS_HEAD_BATCHES 4  // batches of MLS_UNROLL loads per thread that may be issued before a row's trie node is looked up
 #endif
@@ -46,6 +49,8 @@ struct MlsArgs {
     // Repetition penalty (0: off) over the tokens of ids[r, pen_from:T).
     float penalty;
     int pen_from;
+    int pen_bm_bytes;      // bytes of the LDS token bitmap (one bit per token of V, rounded up to 16)
+    int pen_vm_bytes;      // bytes of the LDS vector masks (one bit per 16-byte vector of a row, in words per thread)
     const int64_t* ids;
     int64_t ids_stride;
     int T;
@@ -168,6 +173,23 @@ __global__ __launch_bounds__(MLS_THREADS) void masked_lsm_kernel(MlsArgs a) {
         v_hi = v_lo + per < nvec ? v_lo + per : nvec;
     }
     const RowStream vp(row, (int64_t)nvec * 16);
+    // Repetition penalty: the row's own tokens are asked for first, so that they arrive ahead of the
+    // opening batches below (loads return in order) and the token bitmap is ready when those land.
+    constexpr int PEN_PER_THREAD = GRX_MAX_PENALTY_TOKENS / MLS_THREADS;
+    static_assert(PEN_PER_THREAD * MLS_THREADS == GRX_MAX_PENALTY_TOKENS, "penalty tokens per thread");
+    int64_t p_tok[PEN_PER_THREAD];
+    auto pen_load_ids = [&]() {
+        const int64_t* __restrict__ ids_row = a.ids + (int64_t)r * a.ids_stride;
+#pragma unroll
+        for (int k = 0; k < PEN_PER_THREAD; ++k) {
+            // uniform guard, clamped index: no lane waits on a branch for its token (a token loaded twice
+            // through the clamp is marked twice, which changes nothing)
+            const int t0 = a.pen_from + k * MLS_THREADS;
+            p_tok[k] = -1;
+            if (t0 < a.T) p_tok[k] = ids_row[t0 + tid < a.T ? t0 + tid : a.T - 1];
+        }
+    };
+    if constexpr (PEN && !SPLIT) pen_load_ids();
     // The opening batches: 64 KB of the row per workgroup are in flight while the node look-up below waits
     // for its dependent scalar loads (about 10 us under load).  With one batch the memory system ran dry
     // behind every look-up -- all of them at once when a launch starts: 370.2 -> 366.5 us per launch.
@@ -219,62 +241,97 @@ __global__ __launch_bounds__(MLS_THREADS) void masked_lsm_kernel(MlsArgs a) {
     // A split row is emitted by whichever workgroup finishes last, which gathers then.
     constexpr int SHIFT = (OUT == OUT_COMPACT) ? 1 : 0;
     int e_tok[MLS_EARLY];
-    float e_val[MLS_EARLY];
+    T e_raw[MLS_EARLY];  // as loaded; converted where it is used, so that nothing here waits for it
     auto gather = [&]() {
+        // Straight-line code, two round trips at most: every lane loads a token (index clamped into the
+        // node's child range), then the logit of that token; lanes without a candidate drop the result.
+        const bool have = code >= 0 && c_n > 0;
+        int tk[MLS_EARLY];
 #pragma unroll
         for (int k = 0; k < MLS_EARLY; ++k) {
             const int i = (OUT == OUT_COMPACT) ? tid * MLS_EARLY + k - SHIFT : tid + k * MLS_THREADS;
-            e_tok[k] = -1;
-            e_val[k] = 0.f;
-            if (i >= 0 && i < c_n) {
-                e_tok[k] = (code == GRX_RES_EOS) ? a.eos : a.tok[c_off + i];
+            tk[k] = 0;
+            if (have) tk[k] = a.tok[c_off + (i < 0 ? 0 : (i < c_n ? i : c_n - 1))];
+        }
+#pragma unroll
+        for (int k = 0; k < MLS_EARLY; ++k) {
+            const int i = (OUT == OUT_COMPACT) ? tid * MLS_EARLY + k - SHIFT : tid + k * MLS_THREADS;
+            if (code == GRX_RES_EOS) tk[k] = a.eos;
+            e_tok[k] = (i >= 0 && i < c_n) ? tk[k] : -1;
 #ifdef MLS_ABL_NOGATHER
-                e_val[k] = 0.f;
+            e_raw[k] = 0;
 #else
-                e_val[k] = E::to_float(row[e_tok[k]]);
+            e_raw[k] = row[e_tok[k] < 0 ? 0 : e_tok[k]];
 #endif
-            }
         }
     };
     if (!SPLIT) gather();
 
-    // Repetition penalty: the distinct tokens of ids[r, pen_from:T) go into an LDS set, and the thread
-    // that put a token there first fetches its raw logit -- all of it now, ahead of the stream, so the
-    // scattered reads (a few hundred per row, anywhere in the row) are in flight together with the
-    // stream's loads instead of standing between the row's log-sum-exp and its output.
-    __shared__ int s_pen[PEN_SLOTS];
+    // Repetition penalty.  The distinct tokens of ids[r, pen_from:T) are marked in an LDS bitmap over
+    // the vocabulary before the stream starts.  The second normaliser needs the raw logit of each of
+    // them, and every one passes through the registers of exactly one thread while the row streams.
+    // A thread knows which of its own vectors hold a marked token from a bit mask it keeps in a
+    // register (one LDS word per 32 of its vectors): the common case, nothing marked in a batch, is a
+    // shift and a compare, and a marked vector is put aside whole -- one 16-byte LDS store into the
+    // thread's own PEN_STASH slots, nothing else inside the loop.  What was put aside is taken apart
+    // after the stream, when the row's maximum and sum are known; a thread with more marked vectors
+    // than slots (a handful per row at a few hundred tokens) reads the surplus from memory again.
+    // No other logit is read twice.  Keys and log-probs of the keep_top selection reuse the same LDS
+    // once the bitmap is final.
+    extern __shared__ __align__(16) unsigned char s_dyn[];
+    __shared__ uint32_t s_sel[PEN ? 4 : GRX_KEEP_TOP_MAX_FANOUT * 2];
     __shared__ float s_pen_red[2][MLS_WAVES];
     constexpr bool pen_on = PEN;  // a.penalty > 0: its own instantiation, so the others carry none of this
-    constexpr int PEN_PER_THREAD = GRX_MAX_PENALTY_TOKENS / MLS_THREADS;
-    static_assert(PEN_PER_THREAD * MLS_THREADS == GRX_MAX_PENALTY_TOKENS, "penalty tokens per thread");
-    float p_raw[PEN_PER_THREAD];
-    unsigned p_first = 0;  // bit k: this thread entered its k-th token into the set (first occurrence)
-    auto pen_collect = [&]() {
-        for (int i = tid; i < PEN_SLOTS; i += MLS_THREADS) s_pen[i] = -1;
+    constexpr bool pen_stream = PEN && VEC && !SPLIT;  // marked values are caught in the stream
+    uint32_t* const s_bm = reinterpret_cast<uint32_t*>(s_dyn);
+    const unsigned char* const s_bm8 = s_dyn;
+    // bit j % 32 of word [j / 32][tid] stands for vector tid + j * MLS_THREADS of the row
+    uint32_t* const s_vmask = reinterpret_cast<uint32_t*>(s_dyn + (PEN ? a.pen_bm_bytes : 0));
+    u32x4* const s_stash = reinterpret_cast<u32x4*>(s_dyn + (PEN ? a.pen_bm_bytes + a.pen_vm_bytes : 0));
+    const float pen_l2 = a.penalty * kLog2e;
+    // sub = sum exp(x_u - m) and add = sum exp(p (x_u - m - log s)) over the distinct penalised tokens u
+    // (log-probs are never positive, so the penalty always multiplies)
+    float pen_sub = 0.f, pen_add = 0.f;
+    auto pen_value = [&](float x, float m, float log_s) {
+        if (x == -INFINITY) return;
+        pen_sub += fast_exp2((x - m) * kLog2e);
+        pen_add += fast_exp2((x - m - log_s) * pen_l2);
+    };
+    // Marks the row's tokens.  FETCH (rows that this workgroup did not stream whole itself: split rows,
+    // rows without 16-byte alignment; called once m and log s are known): the thread that marks a
+    // token first reads its logit from memory.
+    auto pen_mark = [&](bool fetch, float m, float log_s) {
+        u32x4* const bm4 = reinterpret_cast<u32x4*>(s_dyn);
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        const int n16 = (a.pen_bm_bytes + (fetch ? 0 : a.pen_vm_bytes)) / 16;
+        for (int i = tid; i < n16; i += MLS_THREADS) bm4[i] = z;
         __syncthreads();
-        const int64_t* __restrict__ ids_row = a.ids + (int64_t)r * a.ids_stride;
 #pragma unroll
         for (int k = 0; k < PEN_PER_THREAD; ++k) {
-            const int t = a.pen_from + tid + k * MLS_THREADS;
-            p_raw[k] = 0.f;
-            if (t >= a.T) continue;
-            const int64_t tk = ids_row[t];
-            if (tk < 0 || tk >= (int64_t)a.V) continue;
-            const int tokv = (int)tk;
-            uint32_t h = ((uint32_t)tokv * 0x9E3779B1u) >> (32 - PEN_SLOT_BITS);
-            for (;;) {
-                const int old = atomicCAS(&s_pen[h], -1, tokv);
-                if (old == -1) {
-                    p_first |= 1u << k;
-                    p_raw[k] = E::to_float(row[tokv]);
-                    break;
+            if (p_tok[k] < 0 || p_tok[k] >= (int64_t)a.V) continue;
+            const int tokv = (int)p_tok[k];
+            const uint32_t bit = 1u << (tokv & 31);
+            if (fetch) {
+                const uint32_t old = atomicOr(&s_bm[tokv >> 5], bit);
+                if (!(old & bit)) pen_value(E::to_float(row[tokv]), m, log_s);
+            } else {
+                atomicOr(&s_bm[tokv >> 5], bit);
+                const int iv = tokv / EPV;
+                if (iv < nvec) {
+                    const int j = iv / MLS_THREADS;
+                    atomicOr(&s_vmask[(j >> 5) * MLS_THREADS + (iv - j * MLS_THREADS)], 1u << (j & 31));
                 }
-                if (old == tokv) break;
-                h = (h + 1) & (PEN_SLOTS - 1);
             }
         }
+        __syncthreads();
     };
-    if (pen_on && !SPLIT) pen_collect();
+    if (pen_stream) pen_mark(false, 0.f, 0.f);
+    // marked elements of vector iv: one bit per element
+    auto pen_bits = [&](int iv) -> uint32_t {
+        if constexpr (E::kPerVec == 8) return s_bm8[iv];
+        else return (s_bm8[iv >> 1] >> ((iv & 1) * 4)) & 0xFu;
+    };
+    int pen_n_hit = 0;  // marked vectors this thread has met in the stream so far
 
     MSTAMP(2);
     // Stream the row once.
@@ -287,32 +344,58 @@ __global__ __launch_bounds__(MLS_THREADS) void masked_lsm_kernel(MlsArgs a) {
         // The dense output of a vectorised launch was filled with -inf by
         // fill_rows_kernel beforehand (write-only and read-only traffic run
         // faster back to back than interleaved), so the stream only reads.
-        auto consume = [&](const u32x4* v, int i) {
+        uint32_t vm = 0;  // the word of s_vmask that covers the current batch
+        auto consume = [&](const u32x4* v, int i, int jb) {  // batch jb of this thread: its vectors 4 jb .. 4 jb + 3
             float f[MLS_UNROLL * E::kPerVec];
 #pragma unroll
             for (int u = 0; u < MLS_UNROLL; ++u) E::unpack(v[u], f + u * E::kPerVec);
             accumulate<MLS_UNROLL * E::kPerVec>(acc, f);
+#ifndef PEN_ABL_NOTEST
+            if constexpr (pen_stream) {
+                static_assert(MLS_UNROLL == 4, "eight batches of four vectors per mask word");
+                if ((jb & 7) == 0) vm = s_vmask[(jb >> 3) * MLS_THREADS + tid];
+                const uint32_t hit = (vm >> ((jb & 7) * 4)) & 0xFu;
+                if (hit) {
+#pragma unroll
+                    for (int u = 0; u < MLS_UNROLL; ++u) {
+                        if (hit & (1u << u)) {
+                            if (pen_n_hit < PEN_STASH) s_stash[pen_n_hit * MLS_THREADS + tid] = v[u];
+                            ++pen_n_hit;
+                        }
+                    }
+                }
+            }
+#endif
         };
 
-        int i = v_lo + tid;
+        int i = v_lo + tid, jb = 0;
 #pragma unroll
         for (int hb = 0; hb < MLS_HEAD_BATCHES; ++hb) {
             if (hb < hbn) {
-                consume(v_head + hb * MLS_UNROLL, i);
+                consume(v_head + hb * MLS_UNROLL, i, hb);
                 i += MLS_UNROLL * MLS_THREADS;
+                jb = hb + 1;
             }
         }
-        for (; i + (MLS_UNROLL - 1) * MLS_THREADS < v_hi; i += MLS_UNROLL * MLS_THREADS) {
+        for (; i + (MLS_UNROLL - 1) * MLS_THREADS < v_hi; i += MLS_UNROLL * MLS_THREADS, ++jb) {
             u32x4 v[MLS_UNROLL];
 #pragma unroll
             for (int u = 0; u < MLS_UNROLL; ++u) v[u] = vp.load(i + u * MLS_THREADS);
-            consume(v, i);
+            consume(v, i, jb);
         }
         for (; i < v_hi; i += MLS_THREADS) {
             const u32x4 v = vp.load(i);
             float f[E::kPerVec];
             E::unpack(v, f);
             accumulate<E::kPerVec>(acc, f);
+            if constexpr (pen_stream) {  // one of the row's last vectors (at most three per thread)
+                const int j = (i - v_lo) / MLS_THREADS;
+                vm = s_vmask[(j >> 5) * MLS_THREADS + tid];
+                if ((vm >> (j & 31)) & 1u) {
+                    if (pen_n_hit < PEN_STASH) s_stash[pen_n_hit * MLS_THREADS + tid] = v;
+                    ++pen_n_hit;
+                }
+            }
         }
     }
     // Elements not covered by 16-byte vectors (all of them when !VEC); the last part of a split row.
@@ -423,33 +506,38 @@ __global__ __launch_bounds__(MLS_THREADS) void masked_lsm_kernel(MlsArgs a) {
     // costs no accuracy that matters at fp32.
     float lse2 = 0.f;
     auto penalised = [&](float y) { return y < 0.f ? y * a.penalty : y / a.penalty; };
-    auto in_pen_set = [&](int tokv) {
-        uint32_t h = ((uint32_t)tokv * 0x9E3779B1u) >> (32 - PEN_SLOT_BITS);
-        for (;;) {
-            const int cur = s_pen[h];
-            if (cur == tokv) return true;
-            if (cur < 0) return false;
-            h = (h + 1) & (PEN_SLOTS - 1);
-        }
-    };
+    auto in_pen_set = [&](int tokv) { return ((s_bm[tokv >> 5] >> (tokv & 31)) & 1u) != 0; };
     if (pen_on) {
-        if (SPLIT) pen_collect();  // the emitting workgroup of a split row collects now
-        float sub = 0.f, add = 0.f;
-#pragma unroll
-        for (int k = 0; k < PEN_PER_THREAD; ++k) {
-            if (p_first & (1u << k)) {
-                const float xm = p_raw[k] - tot.m;
-                sub += fast_exp2(xm * kLog2e);
-                add += fast_exp2(penalised(xm - log_s) * kLog2e);
+        if constexpr (pen_stream) {
+            // the vectors this thread put aside, in stream order = the order of the bits of its mask words
+            int k = 0;
+            for (int w = 0; w * MLS_THREADS * 4 < a.pen_vm_bytes; ++w) {
+                uint32_t word = s_vmask[w * MLS_THREADS + tid];
+                while (word) {
+                    const int iv = tid + (w * 32 + __ffs((int)word) - 1) * MLS_THREADS;
+                    word &= word - 1;
+                    const u32x4 vec = k < PEN_STASH ? s_stash[k * MLS_THREADS + tid] : vp.load(iv);
+                    ++k;
+                    uint32_t b = pen_bits(iv);
+                    while (b) {
+                        pen_value(E::element(vec, __ffs((int)b) - 1), tot.m, log_s);
+                        b &= b - 1;
+                    }
+                }
             }
+            // marked elements behind the row's last whole vector
+            for (int e = nvec * EPV + tid; e < a.V; e += MLS_THREADS)
+                if ((s_bm[e >> 5] >> (e & 31)) & 1u) pen_value(E::to_float(row[e]), tot.m, log_s);
+        } else {
+            if (SPLIT) pen_load_ids();
+            pen_mark(true, tot.m, log_s);
         }
-        sub = wave_sum(sub);
-        add = wave_sum(add);
+        float sub = wave_sum(pen_sub), add = wave_sum(pen_add);
         if ((tid & (GRX_WAVE - 1)) == 0) {
             s_pen_red[0][tid / GRX_WAVE] = sub;
             s_pen_red[1][tid / GRX_WAVE] = add;
         }
-        __syncthreads();  // also publishes the finished token set
+        __syncthreads();
         sub = 0.f;
         add = 0.f;
 #pragma unroll
@@ -486,15 +574,15 @@ __global__ __launch_bounds__(MLS_THREADS) void masked_lsm_kernel(MlsArgs a) {
             // to it in candidate order until keep_top entries are placed.  The kept entries come out in no
             // particular order: the beam step does not need one.
             constexpr int KPL = GRX_KEEP_TOP_MAX_FANOUT / GRX_WAVE;  // keys per lane of wave 0, at most
-            static_assert(PEN_SLOTS * sizeof(int) >= GRX_KEEP_TOP_MAX_FANOUT * 8, "LDS block too small");
-            uint32_t* const s_key = reinterpret_cast<uint32_t*>(s_pen);
-            float* const s_lp = reinterpret_cast<float*>(s_pen + GRX_KEEP_TOP_MAX_FANOUT);
+            // (penalty instantiation: the bitmap's LDS, at least GRX_KEEP_TOP_MAX_FANOUT * 8 bytes by launch)
+            uint32_t* const s_key = PEN ? reinterpret_cast<uint32_t*>(s_dyn) : s_sel;
+            float* const s_lp = reinterpret_cast<float*>(s_key + GRX_KEEP_TOP_MAX_FANOUT);
             const int keep = a.keep_top;
             const float bias = a.row_bias ? a.row_bias[r] : 0.f;
             float lp0 = 0.f, lp1 = 0.f;
             const int i0 = tid * 2 - 1, i1 = tid * 2;
-            if (i0 >= 0 && i0 < c_n) lp0 = final_logp(e_tok[0], e_val[0] - tot.m);
-            if (i1 < c_n) lp1 = final_logp(e_tok[1], e_val[1] - tot.m);
+            if (i0 >= 0 && i0 < c_n) lp0 = final_logp(e_tok[0], E::to_float(e_raw[0]) - tot.m);
+            if (i1 < c_n) lp1 = final_logp(e_tok[1], E::to_float(e_raw[1]) - tot.m);
             constexpr int FIRST = 2 * MLS_THREADS - 1;  // candidates gathered up front
             constexpr int XTRA = (GRX_KEEP_TOP_MAX_FANOUT - FIRST + MLS_THREADS - 1) / MLS_THREADS;
             float lpx[XTRA];
@@ -509,7 +597,7 @@ __global__ __launch_bounds__(MLS_THREADS) void masked_lsm_kernel(MlsArgs a) {
                     }
                 }
             }
-            __syncthreads();  // the penalty set has been consulted for the last time
+            __syncthreads();  // the penalty bitmap has been consulted for the last time
             if (i0 >= 0 && i0 < c_n) {
                 s_lp[i0] = lp0;
                 s_key[i0] = float_to_ordered(lp0 + bias);
@@ -565,7 +653,7 @@ __global__ __launch_bounds__(MLS_THREADS) void masked_lsm_kernel(MlsArgs a) {
 #else
             if (e < n_line) {  // n_line is even, so the pair is inside the row
 #endif
-                cand_store2(crow + e, entry(e, e_tok[0], e_val[0] - tot.m), entry(e + 1, e_tok[1], e_val[1] - tot.m));
+                cand_store2(crow + e, entry(e, e_tok[0], E::to_float(e_raw[0]) - tot.m), entry(e + 1, e_tok[1], E::to_float(e_raw[1]) - tot.m));
             }
         }
 #ifdef MLS_ABL_NOSTORE
@@ -587,7 +675,7 @@ __global__ __launch_bounds__(MLS_THREADS) void masked_lsm_kernel(MlsArgs a) {
 #pragma unroll
         for (int k = 0; k < MLS_EARLY; ++k) {
             const int i = tid + k * MLS_THREADS;
-            if (i < c_n) put(e_tok[k], final_logp(e_tok[k], e_val[k] - tot.m));
+            if (i < c_n) put(e_tok[k], final_logp(e_tok[k], E::to_float(e_raw[k]) - tot.m));
         }
         for (int i = tid + MLS_EARLY * MLS_THREADS; i < c_n; i += MLS_THREADS) {
             const int tok = a.tok[c_off + i];  // an EOS-only row has c_n == 1 and never gets here
@@ -734,15 +822,24 @@ extern "C" int grx_read_probe(const void* rows, int64_t stride_bytes, int32_t R,
 }
 
 // ---- launch -------------------------------------------------------------------
+// Dynamic LDS of the penalty instantiation: token bitmap, per-thread vector masks, PEN_STASH 16-byte
+// slots per thread; never less than the keep_top selection needs when it takes the block over.
+#define PEN_MAX_V GRX_MAX_PENALTY_VOCAB  // the bitmap and vector masks of a wider vocabulary would not fit a workgroup's LDS
+static unsigned pen_lds_bytes(int bm_bytes, int vm_bytes) {
+    const unsigned need = (unsigned)bm_bytes + (unsigned)vm_bytes + PEN_STASH * MLS_THREADS * 16u;
+    return need < GRX_KEEP_TOP_MAX_FANOUT * 8u ? GRX_KEEP_TOP_MAX_FANOUT * 8u : need;
+}
+
 // With events the dispatch itself carries them (start/stop timestamps of this
 // kernel only, no extra packets on the stream).
 template <typename KernelT>
 static void launch_one(KernelT kernel, const MlsArgs& a, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
     const dim3 grid((unsigned)a.R * (unsigned)(a.S > 1 ? a.S : 1));
+    const unsigned lds = a.penalty > 0.f ? pen_lds_bytes(a.pen_bm_bytes, a.pen_vm_bytes) : 0u;
     if (ev0 || ev1)
-        hipExtLaunchKernelGGL(kernel, grid, dim3(MLS_THREADS), 0, stream, ev0, ev1, 0, a);
+        hipExtLaunchKernelGGL(kernel, grid, dim3(MLS_THREADS), lds, stream, ev0, ev1, 0, a);
     else
-        hipLaunchKernelGGL(kernel, grid, dim3(MLS_THREADS), 0, stream, a);
+        hipLaunchKernelGGL(kernel, grid, dim3(MLS_THREADS), lds, stream, a);
 }
 
 template <int DT, int OUT, bool VEC, bool SPLIT>
@@ -798,6 +895,9 @@ static int run_step(const char* who, const grx_trie* trie, grx_state* state, con
         GRX_REQUIRE(con->penalty_skip >= 0, GRX_E_INVALID, "%s: penalty_skip must be >= 0", who);
         GRX_REQUIRE(rows->T - con->penalty_skip <= GRX_MAX_PENALTY_TOKENS, GRX_E_UNSUPPORTED,
                     "%s: repetition penalty over more than %d tokens per row", who, GRX_MAX_PENALTY_TOKENS);
+        GRX_REQUIRE(rows->V <= PEN_MAX_V, GRX_E_UNSUPPORTED,
+                    "%s: the fused repetition penalty serves vocabularies of up to %d tokens (this one: %d)", who,
+                    PEN_MAX_V, rows->V);
     }
     GRX_REQUIRE(con->keep_top >= 0 && con->keep_top <= BS_KEEP_CAP, GRX_E_INVALID, "%s: keep_top must be in [0, %d]", who,
                 BS_KEEP_CAP);
@@ -825,6 +925,12 @@ static int run_step(const char* who, const grx_trie* trie, grx_state* state, con
     if (penalise) {
         a.penalty = con->repetition_penalty;
         a.pen_from = con->penalty_skip;
+        a.pen_bm_bytes = ((rows->V + 127) / 128) * 16;
+        {   // a thread owns every MLS_THREADS-th vector of the row: one mask word per 32 of them
+            const int nvec = rows->V / (16 / (int)dtype_size(rows->dtype));
+            const int per_thread = (nvec + MLS_THREADS - 1) / MLS_THREADS;
+            a.pen_vm_bytes = ((per_thread + 31) / 32) * MLS_THREADS * 4;
+        }
     }
     a.R = rows->R;
     a.scores = rows->scores;

@@ -131,7 +131,9 @@ typedef struct grx_constraint {
      * runs it ahead of the reference's processor when repetition_penalty != 1
      * (evaluate.py:218,363-371).  1.0 (or 0) switches it off.  Tokens of
      * input_ids[:, penalty_skip:] are penalised; rows may hold at most
-     * GRX_MAX_PENALTY_TOKENS tokens then. */
+     * GRX_MAX_PENALTY_TOKENS tokens then, and V at most GRX_MAX_PENALTY_VOCAB (a
+     * workgroup marks the row's tokens in a bitmap over the vocabulary that has to
+     * fit its LDS). */
     float repetition_penalty;
     int32_t penalty_skip;     /* prompt_ignore_length of the HF processor; 0 = none  */
     /* 1: the caller vouches that every row of `scores` already is a log-softmax
@@ -158,6 +160,7 @@ typedef struct grx_constraint {
     const float* row_bias;    /* device fp32 [R] or NULL; read only when keep_top > 0 */
 } grx_constraint;
 #define GRX_MAX_PENALTY_TOKENS 1536
+#define GRX_MAX_PENALTY_VOCAB 320000
 
 /* Bytes of device scratch the two calls below need for R rows (required when
  * R > 0).  It holds the per-row plans that a small kernel writes ahead of the

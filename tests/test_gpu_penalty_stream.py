@@ -1,0 +1,126 @@
+"""The fused repetition penalty of the streaming kernel on rows that are streamed whole by one workgroup
+(more than 256 rows): the penalised tokens' logits are taken out of the registers of the thread that
+streams them.  Checked against a float64 evaluation of the chain generate() runs
+(log_softmax -> RepetitionPenaltyLogitsProcessor -> reference processor; evaluate.py:218,363-371,
+logit_processor.py:29-49) on histories built to stress the extraction: many duplicates, the maximum
+number of distinct tokens, every token falling to one thread, tokens in the element tail behind the
+last 16-byte vector, rows that are not 16-byte aligned, all three element types."""
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+FP32_TOL = 1e-5
+
+
+def _dev():
+    return torch.device("cuda", 0)
+
+
+def _trie(V, fan, seed):
+    """A two-level trie below the prefix whose first-level tokens are spread over the whole vocabulary."""
+    rng = np.random.default_rng(seed)
+    first = np.sort(rng.choice(np.arange(20, V), size=fan, replace=False))
+    seqs = []
+    for t in first:
+        for u in rng.choice(np.arange(20, V), size=2, replace=False):
+            seqs.append([11, 12, 13, int(t), int(u), 2])
+    return seqs, first
+
+
+def _expected(ids, logits64, penalty, skip, allowed):
+    from oracle.processors import ref_repetition_penalty
+
+    lp = torch.log_softmax(logits64, dim=-1)
+    lp = ref_repetition_penalty(ids, lp, penalty, skip)
+    lp = torch.log_softmax(lp, dim=-1)
+    return lp[:, allowed]
+
+
+def _histories(kind, rows, hist_len, V, first, rng):
+    if kind == "random":
+        return rng.integers(0, V, size=(rows, hist_len))
+    if kind == "duplicates":  # few distinct tokens, each many times; half of them allowed tokens
+        pool = np.concatenate([first[:8], rng.integers(0, V, size=8)])
+        return pool[rng.integers(0, len(pool), size=(rows, hist_len))]
+    if kind == "one_thread":  # tokens 2048 apart: every vector that holds one is loaded by the same thread
+        base = rng.integers(0, 8, size=(rows, 1))
+        return (base + 2048 * rng.integers(0, max(1, V // 2048), size=(rows, hist_len))) % V
+    if kind == "tail":  # the last tokens of the vocabulary (behind the last whole vector when V is ragged)
+        return V - 1 - rng.integers(0, 12, size=(rows, hist_len))
+    if kind == "one_vector":  # all eight tokens of single vectors
+        start = 8 * rng.integers(0, V // 8 - 1, size=(rows, 1))
+        return start + rng.integers(0, 8, size=(rows, hist_len))
+    raise AssertionError(kind)
+
+
+@pytest.mark.parametrize("V,dtype,kind,hist_len,penalty", [
+    (8192, torch.float32, "random", 200, 1.1),
+    (8192, torch.bfloat16, "random", 1533, 1.3),      # the longest history the kernel accepts (1536 with the prefix)
+    (8192, torch.float16, "duplicates", 300, 1.1),
+    (8192, torch.float32, "one_thread", 64, 0.8),
+    (8200 - 3, torch.float32, "tail", 40, 1.2),        # rows of 8197 fp32 elements: element-wise instantiation
+    (8192 + 4, torch.bfloat16, "tail", 40, 1.2),       # 16-byte aligned rows with a 4-element tail
+    (8192, torch.bfloat16, "one_vector", 100, 1.1),
+    (152640, torch.bfloat16, "random", 253, 1.1),      # the evaluation shape's row
+    (152640, torch.float32, "duplicates", 253, 1.1),
+])
+def test_streamed_rows_with_penalty_match_the_float64_chain(V, dtype, kind, hist_len, penalty):
+    from genrec_amd.logit_processor import ConstrainedLogitsProcessor
+    from genrec_amd.trie import FlatTrie, create_prefix_allowed_tokens_fn
+
+    dev = _dev()
+    rows = 320  # above the split-row limit: one workgroup streams a row from end to end
+    seqs, first = _trie(V, 90, seed=V % 1000)
+    fn = create_prefix_allowed_tokens_fn(FlatTrie(seqs), [11, 12, 13])
+    rng = np.random.default_rng(hist_len + V)
+    hist = _histories(kind, rows, hist_len, V, first, rng)
+    ids = torch.from_numpy(np.concatenate([hist, np.tile([11, 12, 13], (rows, 1))], axis=1).astype(np.int64))
+    skip = 5 if kind == "random" else 0
+    g = torch.Generator().manual_seed(V + hist_len)
+    logits = (torch.randn(rows, V, generator=g) * 4.0).to(dtype)
+    if kind in ("duplicates", "tail"):  # the row's maximum is a penalised token
+        logits[torch.arange(rows), ids[:, 7]] += 30.0
+        logits = logits.to(dtype)
+    allowed = torch.from_numpy(first.astype(np.int64))
+    want = _expected(ids, logits.double(), penalty, skip, allowed)
+    proc = ConstrainedLogitsProcessor(fn, 16, 3, None, 2, sync_errors=True, repetition_penalty=penalty,
+                                      prompt_ignore_length=skip)
+    proc.count = 0
+    cand = proc.candidates(ids.to(dev), logits.to(dev))
+    assert torch.equal(cand.count.cpu(), torch.full((rows,), len(first), dtype=cand.count.dtype))
+    assert torch.equal(cand.tokens.cpu()[:, : len(first)].long(), allowed[None, :].expand(rows, -1))
+    got = cand.logp.cpu()[:, : len(first)].double()
+    assert float((got - want).abs().max()) <= FP32_TOL
+    # the dense form carries the same values
+    proc.count = 0
+    dense = proc(ids.to(dev), logits.to(dev)).float().cpu()
+    assert int(torch.isfinite(dense).sum()) == rows * len(first)
+    err = (dense[:, allowed].double() - got).abs()
+    if dtype == torch.float32:
+        assert float(err.max()) <= 4e-6
+    else:  # the dense result is rounded to the input's 16-bit type: half an ulp of the value
+        assert bool((err <= got.abs() * 2.0 ** -8 + 1e-6).all())
+    # split rows (the same rows, few enough of them that several workgroups share one)
+    proc.count = 0
+    few = proc.candidates(ids[:32].to(dev), logits[:32].to(dev))
+    assert float((few.logp.cpu()[:, : len(first)].double() - want[:32]).abs().max()) <= FP32_TOL
+
+
+def test_vocabulary_too_wide_for_the_bitmap_is_refused():
+    from genrec_amd import _lib
+    from genrec_amd.logit_processor import ConstrainedLogitsProcessor
+    from genrec_amd.trie import FlatTrie, create_prefix_allowed_tokens_fn
+
+    dev = _dev()
+    V = 400_008
+    fn = create_prefix_allowed_tokens_fn(FlatTrie([[11, 12, 13, 50, 2]]), [11, 12, 13])
+    ids = torch.tensor([[5, 6, 11, 12, 13]] * 2, device=dev)
+    x = torch.zeros((2, V), device=dev)
+    proc = ConstrainedLogitsProcessor(fn, 2, 3, None, 2, sync_errors=True, repetition_penalty=1.1)
+    with pytest.raises(_lib.GenrecHipError):
+        proc.candidates(ids, x)
+    plain = ConstrainedLogitsProcessor(fn, 2, 3, None, 2, sync_errors=True)
+    assert int(plain.candidates(ids, x).count[0]) == 1

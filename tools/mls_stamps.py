@@ -20,18 +20,20 @@ from genrec_amd.trie import build_trie_from_index, create_prefix_allowed_tokens_
 from genrec_amd.synth import write_index_file  # noqa: E402
 
 dev = torch.device("cuda", 0)
-path = write_index_file("Instruments", tempfile.mkdtemp())
+path = write_index_file(os.environ.get("ST_TRIE", "Instruments"), tempfile.mkdtemp())
 tok = SidTokenizer.from_index(path)
 trie, suffix, pidx = build_trie_from_index(path, tok, prefix=ASSISTANT_PREFIX)
 fn = create_prefix_allowed_tokens_fn(trie, suffix)
-V, K = tok.vocab_size_padded, 16
+V, K = tok.vocab_size_padded, int(os.environ.get("ST_BEAMS", 16))
+PEN = float(os.environ.get("ST_PENALTY", 1.0))
+PROMPT = int(os.environ.get("ST_PROMPT", 61))
 h = _lib.lib()
 h.grx_debug_read_mls_stamps.argtypes = [C.c_void_p]
-proc = ConstrainedLogitsProcessor(fn, K, pidx, None, tok.eos_token_id)
+proc = ConstrainedLogitsProcessor(fn, K, pidx, None, tok.eos_token_id, **({"repetition_penalty": PEN} if PEN != 1.0 else {}))
 names = ["start->head issued+resolve", "resolve->gather issued", "stream", "combine", "merge/logf", "emit+ack"]
 for R in [int(x) for x in os.environ.get("ST_ROWS", "16,256,8192").split(",")]:
     step = int(os.environ.get("ST_STEP", 1))
-    ids = torch.from_numpy(sample_decode_rows(trie, R // K, K, step, seed=1)).to(dev)
+    ids = torch.from_numpy(sample_decode_rows(trie, R // K, K, step, prompt_len=PROMPT, seed=1)).to(dev)
     x = (torch.randn((R, V), device=dev) * 4).to(torch.bfloat16)
     cand = Candidates(R, trie.max_fanout, dev)
     for _ in range(3):
@@ -45,6 +47,7 @@ for R in [int(x) for x in os.environ.get("ST_ROWS", "16,256,8192").split(",")]:
     live = st[:, 0] > 0
     st = st[live]
     t0 = st[:, 0].min()
+    print(f"penalty={PEN} step={step}", end=" ")
     print(f"R={R}: {len(st)} workgroups stamped; kernel span {(st[:, 6].max() - t0) / 100:.1f} us "
           f"(first start -> last end); start spread {(st[:, 0].max() - t0) / 100:.1f} us")
     for i, nm in enumerate(names):
