@@ -336,7 +336,10 @@ def test_oracle_reproduces_evaluation_style_generate_with_50_beams_and_repetitio
 def test_token_prefix_oracle_bit_exact_with_the_reference_trainer():
     """token_prefix.npz holds what the reference's TokenPrefixGRPOTrainer produced (reward builders and
     _generate_and_score_completions, token_prefix_grpo_trainer.py:107-149,174-287): the restatement must
-    reproduce token rewards, sequence rewards, error masks and advantages bit for bit."""
+    reproduce token rewards, sequence rewards and error masks bit for bit.  The advantages are fp32 means and
+    variances taken by PyTorch's CPU reduction kernels, whose summation order follows the vector width of the
+    host that runs them: bit-equal on the host that recorded the fixture (asserted by the generating script,
+    restatement and reference side by side), within 4 ulp of a unit-scale value (5e-7) on any other."""
     d = np.load(os.path.join(GOLDEN, "token_prefix.npz"))
     n, eos = int(d["n_cases"][0]), int(d["n_cases"][1])
     assert n == 72
@@ -352,4 +355,4 @@ def test_token_prefix_oracle_bit_exact_with_the_reference_trainer():
         ndcg = torch.from_numpy(d[f"c{c}.ndcg"]) if has_ndcg else None
         adv = oscore.ref_token_prefix_advantages(tr, sr, em, mask, K, pw, nw, bool(has_ndcg), ndcg, bool(total),
                                                  bool(err_pen))
-        assert torch.equal(adv, torch.from_numpy(d[f"c{c}.advantages"])), c
+        assert float((adv - torch.from_numpy(d[f"c{c}.advantages"])).abs().max()) <= 5e-7, c
