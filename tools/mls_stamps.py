@@ -38,7 +38,7 @@ for R in [int(x) for x in os.environ.get("ST_ROWS", "16,256,8192").split(",")]:
     cand = Candidates(R, trie.max_fanout, dev)
     for _ in range(3):
         proc.count = step
-        proc.candidates_into(ids, x, cand)
+        proc.candidates_into(ids, x, cand, keep_top=int(os.environ.get("ST_KEEP", 0)))
     torch.cuda.synchronize()
     buf = np.zeros(4096 * 8, dtype=np.uint64)
     assert h.grx_debug_read_mls_stamps(buf.ctypes.data) == 0
