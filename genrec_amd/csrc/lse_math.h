@@ -218,3 +218,55 @@ __device__ __forceinline__ MaxSum block_combine(MaxSum a, float* s_m, float* s_s
     r.c = bc;
     return r;
 }
+
+// block_combine for a row with a repetition penalty.  Besides its share (m, s, c) of the row a thread
+// brings sub = sum 2^(x_u log2e + c) and add = sum 2^(p (x_u log2e + c)) over the penalised elements x_u
+// it streamed itself (x_u <= m, so neither overflows).  They are brought to the wave's and then to the
+// workgroup's offset like s -- add with the factor raised to the power p -- and come back as
+// sub = sum exp(x_u - m) and add = sum 2^(p (x_u log2e + r.c)); the caller finishes add once log s is known.
+struct PenSums {
+    float sub, add;
+};
+
+__device__ __forceinline__ MaxSum block_combine_pen(MaxSum a, float p, PenSums& ps, float* s_m, float* s_s,
+                                                    float (*s_pen)[MLS_WAVES]) {
+    const int lane = threadIdx.x & (GRX_WAVE - 1);
+    const int wave = threadIdx.x / GRX_WAVE;
+    const float M = wave_max(a.m);
+    const float C = (M == -INFINITY) ? 0.f : -M * kLog2e;
+    const bool live = a.s > 0.f;
+    const float d = live ? C - a.c : 0.f;  // <= 0
+    const float S = wave_sum(live ? a.s * fast_exp2(d) : 0.f);
+    const float SUB = wave_sum(live ? ps.sub * fast_exp2(d) : 0.f);
+    const float ADD = wave_sum(live ? ps.add * fast_exp2(p * d) : 0.f);
+    if (lane == 0) {
+        s_m[wave] = M;
+        s_s[wave] = S;
+        s_pen[0][wave] = SUB;
+        s_pen[1][wave] = ADD;
+    }
+    __syncthreads();
+    float bm = s_m[0];
+#pragma unroll
+    for (int w = 1; w < MLS_WAVES; ++w) bm = fmaxf(bm, s_m[w]);
+    const float bc = (bm == -INFINITY) ? 0.f : -bm * kLog2e;
+    float bs = 0.f, bsub = 0.f, badd = 0.f;
+#pragma unroll
+    for (int w = 0; w < MLS_WAVES; ++w) {
+        const float wc = (s_m[w] == -INFINITY) ? 0.f : -s_m[w] * kLog2e;
+        if (s_s[w] > 0.f) {
+            const float g = bc - wc;
+            bs += s_s[w] * fast_exp2(g);
+            bsub += s_pen[0][w] * fast_exp2(g);
+            badd += s_pen[1][w] * fast_exp2(p * g);
+        }
+    }
+    MaxSum r;
+    r.m = bm;
+    const float unres = (bm == -INFINITY) ? 1.f : fast_exp2(-fmaf(bm, kLog2e, bc));
+    r.s = bs * unres;
+    r.c = bc;
+    ps.sub = bsub * unres;
+    ps.add = badd;
+    return r;
+}

@@ -22,6 +22,9 @@ enum { OUT_COMPACT = 0, OUT_FULL_F32 = 1, OUT_FULL_SAME = 2 };
 #ifndef PEN_STASH
 #define PEN_STASH 4  // 16-byte LDS slots per thread for vectors that hold penalised tokens (repetition penalty)
 #endif
+#ifndef PEN_POOL
+#define PEN_POOL 48  // ... and spare slots shared by the workgroup, for the few threads that meet more
+#endif
 #ifndef MLS_HEAD_BATCHES
 #define MLS_HEAD_BATCHES 4  // batches of MLS_UNROLL loads per thread that may be issued before a row's trie node is looked up
 #endif
@@ -186,7 +189,9 @@ __global__ __launch_bounds__(MLS_THREADS) void masked_lsm_kernel(MlsArgs a) {
             // through the clamp is marked twice, which changes nothing)
             const int t0 = a.pen_from + k * MLS_THREADS;
             p_tok[k] = -1;
+#ifndef PEN_ABL_NOIDS
             if (t0 < a.T) p_tok[k] = ids_row[t0 + tid < a.T ? t0 + tid : a.T - 1];
+#endif
         }
     };
     if constexpr (PEN && !SPLIT) pen_load_ids();
@@ -288,6 +293,11 @@ __global__ __launch_bounds__(MLS_THREADS) void masked_lsm_kernel(MlsArgs a) {
     // bit j % 32 of word [j / 32][tid] stands for vector tid + j * MLS_THREADS of the row
     uint32_t* const s_vmask = reinterpret_cast<uint32_t*>(s_dyn + (PEN ? a.pen_bm_bytes : 0));
     u32x4* const s_stash = reinterpret_cast<u32x4*>(s_dyn + (PEN ? a.pen_bm_bytes + a.pen_vm_bytes : 0));
+    // the workgroup's spare slots: a thread whose own slots are full takes up to two of these (numbered by
+    // an LDS counter) before it falls back on reading a vector from memory a second time
+    u32x4* const s_pool = s_stash + PEN_STASH * MLS_THREADS;
+    __shared__ int s_pool_n;
+    int pool_slot0 = -1, pool_slot1 = -1;
     const float pen_l2 = a.penalty * kLog2e;
     // sub = sum exp(x_u - m) and add = sum exp(p (x_u - m - log s)) over the distinct penalised tokens u
     // (log-probs are never positive, so the penalty always multiplies)
@@ -305,6 +315,7 @@ __global__ __launch_bounds__(MLS_THREADS) void masked_lsm_kernel(MlsArgs a) {
         const u32x4 z = {0u, 0u, 0u, 0u};
         const int n16 = (a.pen_bm_bytes + (fetch ? 0 : a.pen_vm_bytes)) / 16;
         for (int i = tid; i < n16; i += MLS_THREADS) bm4[i] = z;
+        if (tid == 0) s_pool_n = 0;
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < PEN_PER_THREAD; ++k) {
@@ -332,6 +343,19 @@ __global__ __launch_bounds__(MLS_THREADS) void masked_lsm_kernel(MlsArgs a) {
         else return (s_bm8[iv >> 1] >> ((iv & 1) * 4)) & 0xFu;
     };
     int pen_n_hit = 0;  // marked vectors this thread has met in the stream so far
+    auto pen_put_aside = [&](const u32x4& vec) {
+        if (pen_n_hit < PEN_STASH) {
+            s_stash[pen_n_hit * MLS_THREADS + tid] = vec;
+        } else if (pen_n_hit < PEN_STASH + 2) {
+            const int slot = atomicAdd(&s_pool_n, 1);
+            if (slot < PEN_POOL) {
+                s_pool[slot] = vec;
+                if (pen_n_hit == PEN_STASH) pool_slot0 = slot;
+                else pool_slot1 = slot;
+            }
+        }
+        ++pen_n_hit;
+    };
 
     MSTAMP(2);
     // Stream the row once.
@@ -358,10 +382,7 @@ __global__ __launch_bounds__(MLS_THREADS) void masked_lsm_kernel(MlsArgs a) {
                 if (hit) {
 #pragma unroll
                     for (int u = 0; u < MLS_UNROLL; ++u) {
-                        if (hit & (1u << u)) {
-                            if (pen_n_hit < PEN_STASH) s_stash[pen_n_hit * MLS_THREADS + tid] = v[u];
-                            ++pen_n_hit;
-                        }
+                        if (hit & (1u << u)) pen_put_aside(v[u]);
                     }
                 }
             }
@@ -391,10 +412,7 @@ __global__ __launch_bounds__(MLS_THREADS) void masked_lsm_kernel(MlsArgs a) {
             if constexpr (pen_stream) {  // one of the row's last vectors (at most three per thread)
                 const int j = (i - v_lo) / MLS_THREADS;
                 vm = s_vmask[(j >> 5) * MLS_THREADS + tid];
-                if ((vm >> (j & 31)) & 1u) {
-                    if (pen_n_hit < PEN_STASH) s_stash[pen_n_hit * MLS_THREADS + tid] = v;
-                    ++pen_n_hit;
-                }
+                if ((vm >> (j & 31)) & 1u) pen_put_aside(v);
             }
         }
     }
@@ -441,7 +459,47 @@ __global__ __launch_bounds__(MLS_THREADS) void masked_lsm_kernel(MlsArgs a) {
     }
     MSTAMP(3);
     MaxSum tot;
-    if (a.skip_stream) {  // the caller's rows are normalised: max-shifted sum 1 at maximum 0, log-sum-exp 0
+    PenSums pen_tot = {0.f, 0.f};
+    if constexpr (pen_stream) {
+        // What this thread put aside is taken apart now, ahead of the workgroup's combine: every marked
+        // element x_u passed through this thread, so it is no larger than the thread's own maximum and
+        // 2^(x_u log2e + c) with the thread's own offset c cannot overflow.  The two sums the second
+        // normaliser needs -- sum 2^(x_u log2e + c) and sum 2^(p (x_u log2e + c)) -- then travel through
+        // the same reductions, and the same single barrier, as the thread's sum of the whole row.
+        auto own_value = [&](float x) {
+            if (x == -INFINITY) return;
+            const float e = fmaf(x, kLog2e, acc.c);
+            pen_tot.sub += fast_exp2(e);
+            pen_tot.add += fast_exp2(a.penalty * e);
+        };
+        int k = 0;  // in stream order = the order of the bits of the thread's mask words
+#ifdef PEN_ABL_NODECODE
+        for (int w = 0; w < 0; ++w) {
+#else
+        for (int w = 0; w * MLS_THREADS * 4 < a.pen_vm_bytes; ++w) {
+#endif
+            uint32_t word = s_vmask[w * MLS_THREADS + tid];
+            while (word) {
+                const int iv = tid + (w * 32 + __ffs((int)word) - 1) * MLS_THREADS;
+                word &= word - 1;
+                u32x4 vec;
+                if (k < PEN_STASH) vec = s_stash[k * MLS_THREADS + tid];
+                else if (k == PEN_STASH && pool_slot0 >= 0) vec = s_pool[pool_slot0];
+                else if (k == PEN_STASH + 1 && pool_slot1 >= 0) vec = s_pool[pool_slot1];
+                else vec = vp.load(iv);  // no slot was left: the one case in which a logit is read twice
+                ++k;
+                uint32_t b = pen_bits(iv);
+                while (b) {
+                    own_value(E::element(vec, __ffs((int)b) - 1));
+                    b &= b - 1;
+                }
+            }
+        }
+        // marked elements behind the row's last whole vector (streamed by this same thread above)
+        for (int e = nvec * EPV + tid; e < a.V; e += MLS_THREADS)
+            if ((s_bm[e >> 5] >> (e & 31)) & 1u) own_value(E::to_float(row[e]));
+        tot = block_combine_pen(acc, a.penalty, pen_tot, s_m, s_s, s_pen_red);  // contains a workgroup barrier
+    } else if (a.skip_stream) {  // the caller's rows are normalised: max-shifted sum 1 at maximum 0, log-sum-exp 0
         tot.m = 0.f;
         tot.s = 1.f;
         tot.c = 0.f;
@@ -508,42 +566,29 @@ __global__ __launch_bounds__(MLS_THREADS) void masked_lsm_kernel(MlsArgs a) {
     auto penalised = [&](float y) { return y < 0.f ? y * a.penalty : y / a.penalty; };
     auto in_pen_set = [&](int tokv) { return ((s_bm[tokv >> 5] >> (tokv & 31)) & 1u) != 0; };
     if (pen_on) {
+        float sub, add;
         if constexpr (pen_stream) {
-            // the vectors this thread put aside, in stream order = the order of the bits of its mask words
-            int k = 0;
-            for (int w = 0; w * MLS_THREADS * 4 < a.pen_vm_bytes; ++w) {
-                uint32_t word = s_vmask[w * MLS_THREADS + tid];
-                while (word) {
-                    const int iv = tid + (w * 32 + __ffs((int)word) - 1) * MLS_THREADS;
-                    word &= word - 1;
-                    const u32x4 vec = k < PEN_STASH ? s_stash[k * MLS_THREADS + tid] : vp.load(iv);
-                    ++k;
-                    uint32_t b = pen_bits(iv);
-                    while (b) {
-                        pen_value(E::element(vec, __ffs((int)b) - 1), tot.m, log_s);
-                        b &= b - 1;
-                    }
-                }
-            }
-            // marked elements behind the row's last whole vector
-            for (int e = nvec * EPV + tid; e < a.V; e += MLS_THREADS)
-                if ((s_bm[e >> 5] >> (e & 31)) & 1u) pen_value(E::to_float(row[e]), tot.m, log_s);
+            // pen_tot.add is relative to the offset the workgroup summed at: 2^(p (x_u log2e + c)) with
+            // m log2e + c = residual, so exp(p (x_u - m - log s)) takes a factor 2^(-p (residual + log2 s))
+            sub = pen_tot.sub;
+            add = pen_tot.add * fast_exp2(-a.penalty * (fmaf(tot.m, kLog2e, tot.c) + log_s * kLog2e));
         } else {
             if (SPLIT) pen_load_ids();
             pen_mark(true, tot.m, log_s);
-        }
-        float sub = wave_sum(pen_sub), add = wave_sum(pen_add);
-        if ((tid & (GRX_WAVE - 1)) == 0) {
-            s_pen_red[0][tid / GRX_WAVE] = sub;
-            s_pen_red[1][tid / GRX_WAVE] = add;
-        }
-        __syncthreads();
-        sub = 0.f;
-        add = 0.f;
+            sub = wave_sum(pen_sub);
+            add = wave_sum(pen_add);
+            if ((tid & (GRX_WAVE - 1)) == 0) {
+                s_pen_red[0][tid / GRX_WAVE] = sub;
+                s_pen_red[1][tid / GRX_WAVE] = add;
+            }
+            __syncthreads();
+            sub = 0.f;
+            add = 0.f;
 #pragma unroll
-        for (int w = 0; w < MLS_WAVES; ++w) {
-            sub += s_pen_red[0][w];
-            add += s_pen_red[1][w];
+            for (int w = 0; w < MLS_WAVES; ++w) {
+                sub += s_pen_red[0][w];
+                add += s_pen_red[1][w];
+            }
         }
         lse2 = logf(fmaxf(tot.s - sub, 0.f) / tot.s + add);
     }
@@ -826,7 +871,7 @@ extern "C" int grx_read_probe(const void* rows, int64_t stride_bytes, int32_t R,
 // slots per thread; never less than the keep_top selection needs when it takes the block over.
 #define PEN_MAX_V GRX_MAX_PENALTY_VOCAB  // the bitmap and vector masks of a wider vocabulary would not fit a workgroup's LDS
 static unsigned pen_lds_bytes(int bm_bytes, int vm_bytes) {
-    const unsigned need = (unsigned)bm_bytes + (unsigned)vm_bytes + PEN_STASH * MLS_THREADS * 16u;
+    const unsigned need = (unsigned)bm_bytes + (unsigned)vm_bytes + (PEN_STASH * MLS_THREADS + PEN_POOL) * 16u;
     return need < GRX_KEEP_TOP_MAX_FANOUT * 8u ? GRX_KEEP_TOP_MAX_FANOUT * 8u : need;
 }
 
