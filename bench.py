@@ -106,6 +106,7 @@ class Rollout:
         self.exchange = None
         self.plan_ahead = not getattr(args, "no_plan_ahead", False)
         self.lazy_turnover = bool(getattr(args, "lazy_turnover", False))
+        self.fused = not getattr(args, "no_fused_step", False)
         self.prompt_rows = wl["prompts"].repeat_interleave(args.beams, dim=0).contiguous()
 
     def new_generation(self):
@@ -130,12 +131,16 @@ class Rollout:
         elif self.depth == wl["levels"] and self.lazy_turnover:
             self.score()
             self.new_generation()
-        flat = self.state.flat_running_sequences()
-        wl["proc"].candidates_into(flat, wl["logits"][self.depth], self.cand, keep_top=self.keep,
-                                   row_bias=self.state.row_bias() if self.keep else None)
-        # the beam kernel plans the next processor call, except after the last level of a generation
+        # the beam step plans the next processor call, except after the last level of a generation
         planner = wl["proc"] if (self.plan_ahead and self.depth + 1 < wl["levels"]) else None
-        self.state.step(self.cand, wl["V"], planner)
+        if self.fused:
+            # one library call per step: a group's beam step runs in the streaming kernel as soon as its rows are done
+            self.state.fused_step(wl["proc"], wl["logits"][self.depth], self.cand, keep_top=self.keep, planner=planner)
+        else:
+            flat = self.state.flat_running_sequences()
+            wl["proc"].candidates_into(flat, wl["logits"][self.depth], self.cand, keep_top=self.keep,
+                                       row_bias=self.state.row_bias() if self.keep else None)
+            self.state.step(self.cand, wl["V"], planner)
         self.depth += 1
         if self.depth == wl["levels"] and not self.lazy_turnover:
             # the generation is complete: its last step scores it and re-initialises the beam state from the
@@ -453,6 +458,8 @@ def main() -> None:
                     help="let every processor call run its own row planning kernel (as under the plain HF loop)")
     ap.add_argument("--no-keep-top", action="store_true",
                     help="rows emit every allowed token instead of their 2 x beams best (A/B of the row truncation)")
+    ap.add_argument("--no-fused-step", action="store_true",
+                    help="processor call and beam step as two library calls (two kernels) instead of one (A/B)")
     ap.add_argument("--lazy-turnover", action="store_true",
                     help="score a finished generation and re-initialise the beam state at the start of the next "
                          "generation's first step instead of at the end of its own last step (A/B)")
@@ -616,7 +623,10 @@ def main() -> None:
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "masked_lsm_kernel (compact output)",
+                "kernel": ("masked_lsm_kernel (compact output)" if (args.no_fused_step or args.beams > 16
+                                                                        or args.repetition_penalty != 1.0)
+                           else "masked_lsm_beam_kernel (compact candidates; a prompt group's beam step runs in the "
+                                "workgroup that emits the group's last row)"),
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

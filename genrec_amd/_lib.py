@@ -39,6 +39,7 @@ EXPORTED_SYMBOLS = (
     "grx_reuse_bytes",
     "grx_constrained_logsoftmax_reuse",
     "grx_constrained_candidates",
+    "grx_constrained_beam_step",
     "grx_candidate_stride",
     "grx_noalloc_max_rows",
     "grx_constrained_candidates_noalloc",
@@ -260,6 +261,10 @@ def _declare(lib: C.CDLL) -> None:
     lib.grx_constrained_candidates.restype = C.c_int
     lib.grx_constrained_candidates.argtypes = [
         vp, vp, C.POINTER(GrxRows), C.POINTER(GrxConstraint), vp, i64, i32, vp, C.c_size_t, vp,
+    ]
+    lib.grx_constrained_beam_step.restype = C.c_int
+    lib.grx_constrained_beam_step.argtypes = [
+        vp, vp, C.POINTER(GrxRows), C.POINTER(GrxConstraint), vp, i64, i32, vp, C.c_size_t, C.POINTER(GrxBeamStepArgs), vp,
     ]
     lib.grx_noalloc_max_rows.restype = i32
     lib.grx_noalloc_max_rows.argtypes = []

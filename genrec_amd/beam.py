@@ -177,15 +177,9 @@ class BeamSearchState:
             )
         return self._step_out
 
-    def step(self, cand, vocab_size: int, planner=None, shared_rows: bool = False) -> BeamStepResult:
-        """Advance by one token from the processor's compact candidates (a ``Candidates`` buffer).
-        ``planner`` (the processor): the kernel also plans the processor's next call on the new
-        running sequences, so that call starts streaming at once.
-
-        ``shared_rows``: ``cand`` holds ONE row per group which all K beams extend from.  Valid
-        whenever the K rows of every group are equal, i.e. at the first step of a search whose beams
-        are copies of one prompt: the results are those of K equal candidate rows, and the
-        processor call that made ``cand`` read 1/K of the logits."""
+    def _step_args(self, cand, vocab_size: int, planner, shared_rows: bool):
+        """The ``grx_beam_step_args`` of the next step (reads the current buffers, writes the others),
+        the objects that must outlive the launch, and whether the kernel plans the next processor call."""
         a = _lib.GrxBeamStepArgs()
         i, o = self.cur, 1 - self.cur
         out = self._outputs()
@@ -215,15 +209,42 @@ class BeamSearchState:
         if plan:
             req, keep = planner.plan_request(self.device, self.B * self.K)
             a.plan_next = C.addressof(req)
+            keep = (req, keep)
+        return a, keep, plan
+
+    def _advance(self, planner, plan: bool) -> BeamStepResult:
+        self.cur = 1 - self.cur
+        self.cur_len += 1
+        if plan:
+            planner.note_planned(self.flat_running_sequences())
+        return self._outputs()
+
+    def step(self, cand, vocab_size: int, planner=None, shared_rows: bool = False) -> BeamStepResult:
+        """Advance by one token from the processor's compact candidates (a ``Candidates`` buffer).
+        ``planner`` (the processor): the kernel also plans the processor's next call on the new
+        running sequences, so that call starts streaming at once.
+
+        ``shared_rows``: ``cand`` holds ONE row per group which all K beams extend from.  Valid
+        whenever the K rows of every group are equal, i.e. at the first step of a search whose beams
+        are copies of one prompt: the results are those of K equal candidate rows, and the
+        processor call that made ``cand`` read 1/K of the logits."""
+        a, keep, plan = self._step_args(cand, vocab_size, planner, shared_rows)
         index = self.device.index if self.device.index is not None else torch.cuda.current_device()
         with torch.cuda.device(index):
             _lib.check(_lib.lib().grx_beam_step(C.byref(a), _lib.current_stream_ptr(self.device)))
         del keep
-        self.cur = o
-        self.cur_len += 1
-        if plan:
-            planner.note_planned(self.flat_running_sequences())
-        return out
+        return self._advance(planner, plan)
+
+    def fused_step(self, processor, scores: torch.Tensor, cand, keep_top: int = 0, planner=None) -> BeamStepResult:
+        """``processor.candidates_into(flat_running_sequences(), scores, cand, keep_top, row_bias())``
+        followed by ``step(cand, vocab, planner)`` as ONE library call (``grx_constrained_beam_step``):
+        where the library can, a prompt group's beam step runs inside the streaming kernel as soon as the
+        group's rows are done.  Same results as the two calls."""
+        a, keep, plan = self._step_args(cand, scores.shape[-1], planner, False)
+        processor.candidates_into(self.flat_running_sequences(), scores, cand, keep_top=keep_top,
+                                  row_bias=self.row_bias() if keep_top else None, beam_step=a)
+        del keep
+        return self._advance(planner, plan)
 
     def has_unfinished(self) -> bool:
         """HF's loop condition (utils.py:3055-3075).  Synchronises."""

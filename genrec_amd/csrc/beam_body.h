@@ -1,0 +1,624 @@
+// One beam-search iteration of one prompt group over compact candidates, as a device function: the body of
+// beam_step_kernel, and the tail of the streaming kernel when that runs a group's step itself.
+#pragma once
+
+#include <math.h>
+
+#include "common.h"
+
+#define BS_THREADS 256
+#define BS_WAVES (BS_THREADS / GRX_WAVE)
+#define BS_MAXK 256
+#define BS_MAXKEEP 512
+#define BS_SURV_CAP 1024       // candidates ranked pairwise after the threshold cut
+#define BS_SMALL_K 16          // the instantiation for common searches: at most this many beams,
+#define BS_SMALL_KEEP 64       // ... kept candidates
+#define BS_SMALL_SURV 512      // ... and survivors
+#define BS_PREFETCH 16         // beams whose candidate rows are fetched in the opening batch of loads
+#define BS_TAIL_K 64           // beams / positions per row of the sequence tails staged in LDS
+#define BS_TAIL_W 16
+
+struct BeamDerived {
+    float fin_div;    // (cur_len + 1 - prompt_len) ** length_penalty
+    float heur_div;   // best_hypothetical_length ** length_penalty
+    int reg_keys;     // every candidate slot is covered by the opening batch of loads: keys stay in registers
+    int tails_in_lds; // the re-ordered parts of the sequence / parent rows fit the LDS tail buffers
+};
+
+// 64-bit sort key: ordered score in the high word; the low word is the
+// complement of (beam << 24 | token), which orders like beam * V + token.
+__device__ __forceinline__ unsigned long long make_key(float score, uint32_t beam, uint32_t tok) {
+    return ((unsigned long long)float_to_ordered(score) << 32) |
+           (unsigned long long)(0xFFFFFFFFu - ((beam << 24) | tok));
+}
+
+__device__ __forceinline__ bool ranks_before(float va, int ia, float vb, int ib) {
+    return va > vb || (va == vb && ia < ib);
+}
+
+#ifndef STAMP
+#define STAMP(n) do { } while (0)
+#endif
+
+// A candidate entry.  COH: the rows were written earlier in this same kernel by other workgroups (with
+// device-scope stores); they are read with device-scope loads, which do not stop at this XCD's L2.
+template <bool COH>
+__device__ __forceinline__ grx_cand cand_load(const grx_cand* p) {
+    if constexpr (COH) {
+        const unsigned long long w = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_AGENT);
+        grx_cand e;
+        e.x = (int32_t)(uint32_t)(w & 0xFFFFFFFFull);
+        e.y = (int32_t)(uint32_t)(w >> 32);
+        return e;
+    } else {
+        return *p;
+    }
+}
+
+// Layout: the candidates of a group are the K x cmax block behind its first row;
+// slot c = beam * cmax + position holds a key, or 0 when position >= count[beam].
+// The LDS arrays are sized by the instantiation: MAXK beams, MAXKEEP kept candidates, SURV_CAP
+// survivors of the threshold cut, tail buffers for TAIL_K beams.  The common search (at most 16
+// beams, 64 kept candidates) gets by with 14 KB where the largest supported one takes 54 KB, and the
+// number of groups a CU works on at once follows from that.
+// b: the group.  Every thread of a 256-thread workgroup must call it.
+template <int MAXK, int MAXKEEP, int SURV_CAP, int TAIL_K, bool COH>
+__device__ __forceinline__ void beam_step_group(const grx_beam_step_args& a, const BeamDerived& d, const PlanCtx& pc,
+                                                grx_row_plan* __restrict__ plan_out, const int b) {
+    __shared__ int s_cnt[MAXK];
+    __shared__ int s_base[MAXK + 1];
+    __shared__ float s_runin[MAXK];
+    __shared__ unsigned char s_fdone_in[MAXK];
+    __shared__ unsigned long long s_tmax[BS_THREADS];
+    __shared__ unsigned long long s_surv[SURV_CAP];
+    __shared__ int s_nsurv;
+    __shared__ unsigned long long s_thresh;
+    __shared__ unsigned long long s_red[2][BS_WAVES];
+    __shared__ float s_score[MAXKEEP];
+    __shared__ int s_parent[MAXKEEP];
+    __shared__ int s_tok[MAXKEEP];
+    __shared__ unsigned char s_hit[MAXKEEP];
+    __shared__ float s_rs[MAXKEEP];
+    __shared__ float s_merged[MAXK + MAXKEEP];
+    __shared__ int s_run_idx[MAXK];
+    __shared__ int s_fin_idx[MAXK];
+    __shared__ float s_newfin[MAXK];
+    __shared__ unsigned char s_newdone[MAXK];
+    __shared__ int64_t s_rseq[TAIL_K * BS_TAIL_W];
+    __shared__ int64_t s_fseq[TAIL_K * BS_TAIL_W];
+    __shared__ int32_t s_rbidx[TAIL_K * BS_TAIL_W];
+    __shared__ int32_t s_fbidx[TAIL_K * BS_TAIL_W];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & (GRX_WAVE - 1);
+    const int wave = tid / GRX_WAVE;
+    const int K = a.K, n_keep = a.n_keep, cmax = a.cmax;
+    const int64_t row0 = (int64_t)b * K;
+    const int L = a.max_length;
+    const int Lg = a.max_length - a.prompt_len;
+    const int gpos = a.cur_len - a.prompt_len;
+    const int w_run = a.cur_len - a.copy_from;        // positions of a running row that move with a re-order
+    const int w_fin = a.cur_len + 1 - a.copy_from;    // ... of a finished row
+    const int slots = K * cmax;
+    STAMP(0);
+
+    // ---- phase A: every global read the step needs is issued before the first wait.
+    // Thread t prefetches one entry of each of the first BS_PREFETCH beams: entry (t - 37 u) mod 256 of
+    // beam u (coalesced, rotated rows).  The rotation spreads short rows over all threads, so that the
+    // per-lane maxima below stay informative when every row holds only a few candidates: unrotated, rows
+    // of c < n_keep entries would leave all but c lanes empty and nothing could be cut.
+    grx_cand pre[BS_PREFETCH];
+    auto pre_col = [&](int u) { return (tid - 37 * u) & (BS_THREADS - 1); };
+    // candidate row of beam k: g_cand + k * bstride (every beam reads the group's one row when they are shared)
+    const int64_t bstride = a.cand_shared ? 0 : a.cand_stride;
+    const grx_cand* __restrict__ g_cand = a.cand + (a.cand_shared ? (int64_t)b : row0) * a.cand_stride;
+    if (d.reg_keys) {
+#pragma unroll
+        for (int u = 0; u < BS_PREFETCH; ++u) {
+            // entries past a beam's count hold stale values; they are masked below
+            pre[u] = cand_load<COH>(g_cand + ((u < K && pre_col(u) < cmax) ? (int64_t)u * bstride + 1 + pre_col(u) : 0));
+        }
+    }
+    for (int k = tid; k < K; k += BS_THREADS) {
+        s_cnt[k] = cand_load<COH>(g_cand + (int64_t)k * bstride).x;
+        s_runin[k] = a.run_score_in[row0 + k];
+        s_fdone_in[k] = a.fin_done_in[row0 + k];
+        s_merged[k] = a.fin_score_in[row0 + k];
+    }
+    const bool unsat_old = a.unsat[b] != 0;
+    if (d.tails_in_lds) {  // K <= BS_TAIL_K rows of at most BS_TAIL_W moving positions: thread = (row, position)
+        const int p = tid & (BS_TAIL_W - 1);
+        for (int k = tid / BS_TAIL_W; k < K; k += BS_THREADS / BS_TAIL_W) {
+            if (p < w_fin) s_fseq[k * BS_TAIL_W + p] = a.fin_seq_in[(row0 + k) * L + a.copy_from + p];
+            if (p < w_run) s_rseq[k * BS_TAIL_W + p] = a.run_seq_in[(row0 + k) * L + a.copy_from + p];
+            if (p < gpos + 1) s_fbidx[k * BS_TAIL_W + p] = a.fin_bidx_in[(row0 + k) * Lg + p];
+            if (p < gpos) s_rbidx[k * BS_TAIL_W + p] = a.run_bidx_in[(row0 + k) * Lg + p];
+        }
+    }
+    if (tid == 0) {
+        s_nsurv = 0;
+        s_thresh = 0;
+    }
+    STAMP(1);
+    __syncthreads();
+    STAMP(2);
+#if defined(BS_ABLATE) && BS_ABLATE == 1
+    if (tid == 0) a.unsat[b] = (unsigned char)(s_cnt[0] + pre[0].x + pre[1].y + (int)s_fseq[0] + s_rbidx[0]);
+    return;
+#endif
+
+    auto key_at = [&](int k, int i, float lp, int tk) -> unsigned long long {
+        return i < s_cnt[k] ? make_key(lp + s_runin[k], (uint32_t)k, (uint32_t)tk) : 0ull;
+    };
+    auto key_of = [&](int c) -> unsigned long long {  // flat slot c = beam * cmax + position
+        const int k = c / cmax, i = c - k * cmax;
+        const grx_cand e = cand_load<COH>(g_cand + (int64_t)k * bstride + 1 + i);
+        return key_at(k, i, __int_as_float(e.y), e.x);
+    };
+    auto emit = [&](int j, unsigned long long key) {
+        if (key == 0) {  // fewer candidates than n_keep: a -inf filler slot
+            s_score[j] = -INFINITY;
+            s_parent[j] = 0;
+            s_tok[j] = 0;
+        } else {
+            const uint32_t packed = 0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull);
+            s_score[j] = ordered_to_float((uint32_t)(key >> 32));
+            s_parent[j] = (int)(packed >> 24);
+            s_tok[j] = (int)(packed & 0xFFFFFFu);
+        }
+    };
+
+    // ---- top n_keep by (score desc, beam * V + token asc).  Keys are unique, so
+    // the rank of a key is the number of larger keys.  Fast path: a threshold
+    // (the n_keep-th largest of the per-thread maxima, which at least n_keep keys
+    // reach) leaves a few dozen survivors; they are ranked against each other.
+    bool selected = false;
+    if (d.reg_keys) {
+        // K <= BS_PREFETCH beams of at most BS_THREADS candidates, n_keep <= 64: thread t holds one entry
+        // of every beam.  64 partition maxima (lane-wise over the four waves) give the threshold.
+        unsigned long long rk[BS_PREFETCH];
+        unsigned long long tmax = 0;
+#pragma unroll
+        for (int u = 0; u < BS_PREFETCH; ++u) {
+            rk[u] = (u < K && pre_col(u) < cmax) ? key_at(u, pre_col(u), __int_as_float(pre[u].y), pre[u].x) : 0ull;
+            tmax = rk[u] > tmax ? rk[u] : tmax;
+        }
+        s_tmax[tid] = tmax;
+        STAMP(3);
+        __syncthreads();
+        if (wave == 0) {
+            unsigned long long pm = s_tmax[lane];
+#pragma unroll
+            for (int w = 1; w < BS_WAVES; ++w) pm = s_tmax[lane + w * GRX_WAVE] > pm ? s_tmax[lane + w * GRX_WAVE] : pm;
+            int rank = 0;  // keys are unique, so the partition maxima are distinct (or 0)
+            const int pm_lo = (int)(unsigned)(pm & 0xFFFFFFFFull), pm_hi = (int)(unsigned)(pm >> 32);
+#pragma unroll
+            for (int j = 0; j < GRX_WAVE; ++j) {  // lane j's value as a scalar: no LDS traffic
+                const unsigned lo = (unsigned)__builtin_amdgcn_readlane(pm_lo, j);
+                const unsigned hi = (unsigned)__builtin_amdgcn_readlane(pm_hi, j);
+                rank += (((unsigned long long)hi << 32) | lo) > pm ? 1 : 0;
+            }
+            if (pm != 0 && rank == n_keep - 1) s_thresh = pm;  // stays 0 when fewer than n_keep partitions hold a key
+        }
+        STAMP(5);
+        __syncthreads();
+        const unsigned long long thresh = s_thresh;
+#pragma unroll
+        for (int u = 0; u < BS_PREFETCH; ++u) {
+            if (rk[u] != 0 && rk[u] >= thresh) {
+                const int at = atomicAdd(&s_nsurv, 1);
+                if (at < SURV_CAP) s_surv[at] = rk[u];
+            }
+        }
+        STAMP(6);
+        __syncthreads();
+        const int M = s_nsurv;
+        if (M <= SURV_CAP) {
+            for (int i = tid; i < M; i += BS_THREADS) {
+                const unsigned long long kv = s_surv[i];
+                int rank = 0;
+#pragma unroll 8
+                for (int j = 0; j < M; ++j) rank += s_surv[j] > kv ? 1 : 0;
+                if (rank < n_keep) emit(rank, kv);
+            }
+            for (int j = M + tid; j < n_keep; j += BS_THREADS) emit(j, 0);
+            selected = true;
+        }
+    } else {
+        // Wider groups: two passes over the existing candidates straight from global memory (they were
+        // written a moment ago and sit in L2) -- per-thread maxima and threshold first, survivors second.
+        // Two ways to deal the candidates to the threads, whichever needs fewer rounds of loads:
+        //  * packed: candidate c of the group (entry c - s_base[k] of beam k, the largest k with
+        //    s_base[k] <= c) goes to thread c mod 256 -- few candidates, few rounds;
+        //  * by column: thread t takes one entry per beam and 256-entry chunk, entry (t - 37 k) mod 256
+        //    of beam k (the rotation spreads short rows over all threads, which keeps the per-thread
+        //    maxima informative) -- the loads of different beams need no index search and are issued
+        //    back to back, which wins when the rows are long.
+        for (int k = tid; k <= K; k += BS_THREADS) {
+            int acc = 0;
+            for (int j = 0; j < k; ++j) acc += s_cnt[j] < cmax ? s_cnt[j] : cmax;
+            s_base[k] = acc;
+        }
+        __syncthreads();
+        const int total = s_base[K];
+        const int n_chunk = (cmax + BS_THREADS - 1) / BS_THREADS;
+        const bool by_column = (total + BS_THREADS - 1) / BS_THREADS > 2 * ((K + 15) / 16) * n_chunk;
+        auto packed_key = [&](int c) -> unsigned long long {
+            int lo = 0, hi = K;
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (s_base[mid] <= c) lo = mid; else hi = mid;
+            }
+            const grx_cand e = cand_load<COH>(g_cand + (int64_t)lo * bstride + 1 + (c - s_base[lo]));
+            return make_key(__int_as_float(e.y) + s_runin[lo], (uint32_t)lo, (uint32_t)e.x);
+        };
+        // keys of the entries that thread `tid` holds for beams k0 .. k0 + 15 in chunk j: the 16 loads
+        // are unconditional (the row header stands in where there is no entry) and issued together
+        constexpr int CB = 16;
+        auto column_keys = [&](int k0, int j, unsigned long long* kv) {
+            grx_cand e[CB];
+            bool ok[CB];
+#pragma unroll
+            for (int u = 0; u < CB; ++u) {
+                const int k = k0 + u < K ? k0 + u : K - 1;
+                const int i = j * BS_THREADS + ((tid - 37 * k) & (BS_THREADS - 1));
+                ok[u] = k0 + u < K && i < (s_cnt[k] < cmax ? s_cnt[k] : cmax);
+                e[u] = cand_load<COH>(g_cand + (int64_t)k * bstride + (ok[u] ? 1 + i : 0));
+            }
+#pragma unroll
+            for (int u = 0; u < CB; ++u) {
+                const int k = k0 + u < K ? k0 + u : K - 1;
+                kv[u] = ok[u] ? make_key(__int_as_float(e[u].y) + s_runin[k], (uint32_t)k, (uint32_t)e[u].x) : 0ull;
+            }
+        };
+        unsigned long long tmax = 0;
+        if (by_column) {
+            for (int j = 0; j < n_chunk; ++j) {
+                for (int k0 = 0; k0 < K; k0 += CB) {
+                    unsigned long long kv[CB];
+                    column_keys(k0, j, kv);
+#pragma unroll
+                    for (int u = 0; u < CB; ++u) tmax = kv[u] > tmax ? kv[u] : tmax;
+                }
+            }
+        } else {
+#pragma unroll 4
+            for (int c = tid; c < total; c += BS_THREADS) {
+                const unsigned long long kv = packed_key(c);
+                tmax = kv > tmax ? kv : tmax;
+            }
+        }
+        s_tmax[tid] = tmax;
+        STAMP(4);
+        __syncthreads();
+        if (tmax != 0) {
+            int rank = 0;
+#pragma unroll 16
+            for (int j = 0; j < BS_THREADS; ++j) rank += s_tmax[j] > tmax ? 1 : 0;
+            if (rank == n_keep - 1) s_thresh = tmax;  // stays 0 when fewer than n_keep threads hold a key
+        }
+        STAMP(5);
+        __syncthreads();
+        const unsigned long long thresh = s_thresh;
+        auto keep = [&](unsigned long long kv) {
+            if (kv != 0 && kv >= thresh) {
+                const int at = atomicAdd(&s_nsurv, 1);
+                if (at < SURV_CAP) s_surv[at] = kv;
+            }
+        };
+        if (by_column) {
+            for (int j = 0; j < n_chunk; ++j) {
+                for (int k0 = 0; k0 < K; k0 += CB) {
+                    unsigned long long kv[CB];
+                    column_keys(k0, j, kv);
+#pragma unroll
+                    for (int u = 0; u < CB; ++u) keep(kv[u]);
+                }
+            }
+        } else {
+#pragma unroll 4
+            for (int c = tid; c < total; c += BS_THREADS) keep(packed_key(c));
+        }
+        STAMP(6);
+        __syncthreads();
+        const int M = s_nsurv;
+        if (M <= SURV_CAP) {
+            for (int i = tid; i < M; i += BS_THREADS) {
+                const unsigned long long kv = s_surv[i];
+                int rank = 0;
+#pragma unroll 8
+                for (int j = 0; j < M; ++j) rank += s_surv[j] > kv ? 1 : 0;
+                if (rank < n_keep) emit(rank, kv);
+            }
+            for (int j = M + tid; j < n_keep; j += BS_THREADS) emit(j, 0);
+            selected = true;
+        }
+    }
+    if (!selected) {
+        // general path: n_keep rounds of "largest key below the previous winner"
+        unsigned long long prev = ~0ull;
+        for (int j = 0; j < n_keep; ++j) {
+            unsigned long long best = 0;
+            if (prev != 0) {
+                for (int c = tid; c < slots; c += BS_THREADS) {
+                    const unsigned long long kv = key_of(c);
+                    if (kv < prev && kv > best) best = kv;
+                }
+                best = wave_max_u64(best);
+                if (lane == 0) s_red[j & 1][wave] = best;
+                __syncthreads();
+                best = s_red[j & 1][0];
+#pragma unroll
+                for (int w = 1; w < BS_WAVES; ++w) best = s_red[j & 1][w] > best ? s_red[j & 1][w] : best;
+            }
+            if (tid == 0) emit(j, best);
+            prev = best;
+        }
+    }
+    STAMP(7);
+    __syncthreads();
+    STAMP(8);
+#if defined(BS_ABLATE) && BS_ABLATE == 2
+    if (tid == 0) a.unsat[b] = (unsigned char)(s_tok[0] + s_parent[1]);
+    return;
+#endif
+
+    // ---- stopping criteria and the two masked score vectors
+    const bool at_max_len = (a.cur_len + 1) >= a.max_length;
+    int n_done = 0;
+#pragma unroll 8
+    for (int k = 0; k < K; ++k) n_done += s_fdone_in[k] != 0 ? 1 : 0;
+    const bool all_done = n_done == K;
+    const bool beams_full = all_done && (a.early_stopping == 1);
+    for (int j = tid; j < n_keep; j += BS_THREADS) {
+        const bool hit = at_max_len || (a.eos_token_id >= 0 && s_tok[j] == a.eos_token_id);
+        s_hit[j] = hit ? 1 : 0;
+        const float sc = s_score[j];
+        s_rs[j] = hit ? sc + (-1.0e9f) : sc;
+        float fs = sc / d.fin_div;
+        if (beams_full) fs += -1.0e9f;
+        if (!unsat_old) fs += -1.0e9f;
+        if (!(hit && j < K)) fs += -1.0e9f;
+        s_merged[K + j] = fs;
+    }
+    STAMP(9);
+    __syncthreads();
+
+    // ---- running top-K (of n_keep) and finished top-K (of K + n_keep) by rank counting
+    const int n_merged = K + n_keep;
+    if (n_merged <= GRX_WAVE) {
+        // both lists fit one wave each: wave 0 ranks the running scores, wave 1 the merged finished
+        // scores, lane j against every lane's value broadcast as a scalar
+        if (wave < 2) {
+            const int n = wave == 0 ? n_keep : n_merged;
+            const float v = lane < n ? (wave == 0 ? s_rs[lane] : s_merged[lane]) : -INFINITY;
+            const int vi = __float_as_int(v);
+            int rank = 0;
+#pragma unroll
+            for (int i = 0; i < GRX_WAVE; ++i) {  // constant lane indices: scalar broadcasts, no LDS traffic
+                const float o = __int_as_float(__builtin_amdgcn_readlane(vi, i));
+                rank += (i < n && ranks_before(o, i, v, lane)) ? 1 : 0;
+            }
+            if (lane < n && rank < K) (wave == 0 ? s_run_idx : s_fin_idx)[rank] = lane;
+        }
+    } else if (n_keep + n_merged <= SURV_CAP) {
+        // Larger lists: (score descending, index ascending) becomes one unique 64-bit key per element --
+        // kept in the survivor buffer, which is free by now -- and the rank of an element is the number
+        // of larger keys: one 64-bit compare per pair instead of three compares and their logic.
+        unsigned long long* const rkey = s_surv;
+        unsigned long long* const mkey = s_surv + n_keep;
+        for (int j = tid; j < n_keep + n_merged; j += BS_THREADS) {
+            const bool running = j < n_keep;
+            const int i = running ? j : j - n_keep;
+            s_surv[j] = ((unsigned long long)float_to_ordered(running ? s_rs[i] : s_merged[i]) << 32) |
+                        (unsigned long long)(0xFFFFFFFFu - (uint32_t)i);
+        }
+        __syncthreads();
+        for (int idx = tid; idx < n_keep + n_merged; idx += BS_THREADS) {  // both lists at once
+            const bool running = idx < n_keep;
+            const unsigned long long* __restrict__ keys = running ? rkey : mkey;
+            const int n = running ? n_keep : n_merged;
+            const int j = running ? idx : idx - n_keep;
+            const unsigned long long mine = keys[j];
+            int rank = 0;
+#pragma unroll 8
+            for (int i = 0; i < n; ++i) rank += keys[i] > mine ? 1 : 0;
+            if (rank < K) (running ? s_run_idx : s_fin_idx)[rank] = j;
+        }
+    } else {
+        for (int j = tid; j < n_keep; j += BS_THREADS) {
+            const float v = s_rs[j];
+            int rank = 0;
+#pragma unroll 8
+            for (int i = 0; i < n_keep; ++i) rank += ranks_before(s_rs[i], i, v, j) ? 1 : 0;
+            if (rank < K) s_run_idx[rank] = j;
+        }
+        for (int j = tid; j < n_merged; j += BS_THREADS) {
+            const float v = s_merged[j];
+            int rank = 0;
+#pragma unroll 8
+            for (int i = 0; i < n_merged; ++i) rank += ranks_before(s_merged[i], i, v, j) ? 1 : 0;
+            if (rank < K) s_fin_idx[rank] = j;
+        }
+    }
+    STAMP(10);
+    __syncthreads();
+    STAMP(11);
+#if defined(BS_ABLATE) && BS_ABLATE == 3
+    if (tid == 0) a.unsat[b] = (unsigned char)(s_run_idx[0] + s_fin_idx[1]);
+    return;
+#endif
+
+    // ---- write the per-step results
+    for (int j = tid; j < n_keep; j += BS_THREADS) {
+        const int64_t o = (int64_t)b * n_keep + j;
+        if (a.topk_score) a.topk_score[o] = s_score[j];
+        if (a.topk_parent) a.topk_parent[o] = s_parent[j];
+        if (a.topk_token) a.topk_token[o] = s_tok[j];
+        if (a.topk_hit) a.topk_hit[o] = s_hit[j];
+    }
+    for (int k = tid; k < K; k += BS_THREADS) {
+        const int j = s_run_idx[k];
+        a.run_score_out[row0 + k] = s_rs[j];
+        a.run_seq_out[(row0 + k) * L + a.cur_len] = (int64_t)s_tok[j];
+        a.run_bidx_out[(row0 + k) * Lg + gpos] = (int)row0 + s_parent[j];
+        if (a.next_parent) a.next_parent[row0 + k] = (int)row0 + s_parent[j];
+
+        const int m = s_fin_idx[k];
+        const float fscore = s_merged[m];
+        unsigned char fdone;
+        if (m < K) {
+            fdone = s_fdone_in[m];
+        } else {
+            const int jj = m - K;
+            fdone = (s_hit[jj] && jj < K) ? 1 : 0;
+            a.fin_seq_out[(row0 + k) * L + a.cur_len] = (int64_t)s_tok[jj];
+            a.fin_bidx_out[(row0 + k) * Lg + gpos] = (int)row0 + s_parent[jj];
+        }
+        a.fin_score_out[row0 + k] = fscore;
+        a.fin_done_out[row0 + k] = fdone;
+        s_newfin[k] = fscore;
+        s_newdone[k] = fdone;
+    }
+
+    // sequence bodies [copy_from, cur_len) (+ position cur_len for carried-over finished rows)
+    // and parent trails [0, gpos) (+ position gpos for carried-over finished rows)
+    if (d.tails_in_lds) {
+        const int p = tid & (BS_TAIL_W - 1);
+        for (int k = tid / BS_TAIL_W; k < K; k += BS_THREADS / BS_TAIL_W) {
+            const int rsrc = s_parent[s_run_idx[k]];
+            const int m = s_fin_idx[k];
+            if (p < w_run) a.run_seq_out[(row0 + k) * L + a.copy_from + p] = s_rseq[rsrc * BS_TAIL_W + p];
+            if (p < gpos) a.run_bidx_out[(row0 + k) * Lg + p] = s_rbidx[rsrc * BS_TAIL_W + p];
+            if (m < K) {
+                if (p < w_fin) a.fin_seq_out[(row0 + k) * L + a.copy_from + p] = s_fseq[m * BS_TAIL_W + p];
+                if (p < gpos + 1) a.fin_bidx_out[(row0 + k) * Lg + p] = s_fbidx[m * BS_TAIL_W + p];
+            } else {
+                const int fsrc = s_parent[m - K];
+                if (p < w_run) a.fin_seq_out[(row0 + k) * L + a.copy_from + p] = s_rseq[fsrc * BS_TAIL_W + p];
+                if (p < gpos) a.fin_bidx_out[(row0 + k) * Lg + p] = s_rbidx[fsrc * BS_TAIL_W + p];
+            }
+        }
+    } else {
+        for (int idx = tid; idx < K * w_run; idx += BS_THREADS) {
+            const int k = idx / w_run, p = idx % w_run;
+            const int src = s_parent[s_run_idx[k]];
+            a.run_seq_out[(row0 + k) * L + a.copy_from + p] = a.run_seq_in[(row0 + src) * L + a.copy_from + p];
+        }
+        for (int idx = tid; idx < K * w_fin; idx += BS_THREADS) {
+            const int k = idx / w_fin, p = idx % w_fin;
+            const int m = s_fin_idx[k];
+            const int64_t at = (row0 + k) * L + a.copy_from + p;
+            if (m < K) {
+                a.fin_seq_out[at] = a.fin_seq_in[(row0 + m) * L + a.copy_from + p];
+            } else if (p < w_run) {
+                a.fin_seq_out[at] = a.run_seq_in[(row0 + s_parent[m - K]) * L + a.copy_from + p];
+            }
+        }
+        for (int idx = tid; idx < K * gpos; idx += BS_THREADS) {
+            const int k = idx / gpos, q = idx % gpos;
+            a.run_bidx_out[(row0 + k) * Lg + q] = a.run_bidx_in[(row0 + s_parent[s_run_idx[k]]) * Lg + q];
+        }
+        for (int idx = tid; idx < K * (gpos + 1); idx += BS_THREADS) {
+            const int k = idx / (gpos + 1), q = idx % (gpos + 1);
+            const int m = s_fin_idx[k];
+            if (m < K) {
+                a.fin_bidx_out[(row0 + k) * Lg + q] = a.fin_bidx_in[(row0 + m) * Lg + q];
+            } else if (q < gpos) {
+                a.fin_bidx_out[(row0 + k) * Lg + q] = a.run_bidx_in[(row0 + s_parent[m - K]) * Lg + q];
+            }
+        }
+    }
+    STAMP(12);
+    __syncthreads();
+    STAMP(13);
+
+    // ---- early-stop heuristic for the next iteration
+    if (K <= GRX_WAVE) {
+        if (wave == 0) {
+            const float best_possible = s_rs[s_run_idx[0]] / d.heur_div;
+            const float mine = lane < K ? s_newfin[lane] : INFINITY;
+            float worst_all = mine;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) worst_all = fminf(worst_all, __shfl_xor(worst_all, o, GRX_WAVE));
+            const float worst = (lane < K && s_newdone[lane]) ? worst_all : -1.0e9f;
+            const bool any = __ballot(lane < K && best_possible > worst) != 0ull;
+            if (lane == 0) a.unsat[b] = (unsat_old && any) ? 1 : 0;
+        }
+    } else if (tid == 0) {
+        const float best_possible = s_rs[s_run_idx[0]] / d.heur_div;
+        float worst_all = s_newfin[0];
+#pragma unroll 8
+        for (int k = 1; k < K; ++k) worst_all = fminf(worst_all, s_newfin[k]);
+        bool any = false;
+#pragma unroll 8
+        for (int k = 0; k < K; ++k) {
+            const float worst = s_newdone[k] ? worst_all : -1.0e9f;
+            any = any || (best_possible > worst);
+        }
+        a.unsat[b] = (unsat_old && any) ? 1 : 0;
+    }
+    STAMP(14);
+
+    // ---- optionally plan the next processor call for the rows this group just produced
+    if (plan_out != nullptr) {
+        // the sequence rows were written by other threads of this workgroup (barrier above STAMP(13))
+        const int T_next = a.cur_len + 1;
+        if (pc.mode == GRX_MODE_COUNT) {
+            // the streaming kernel walks the rows itself; what it needs from here is the once-per-call
+            // bookkeeping and the lowest row that ends in prefix_ids
+            if (b == 0 && tid == 0) plan_count_bookkeeping(pc);
+            for (int k = tid; k < K; k += BS_THREADS)
+                count_row_match(pc, a.run_seq_out + (row0 + k) * L, T_next, (int)(row0 + k));
+        } else {
+            // Fixed-hint mode.  A new row is its parent's row plus one token, so its first valid prefix
+            // occurrence is the parent's whenever the parent's node continues with that token onto a
+            // node that has children: occurrences before the parent's stay invalid with one more token.
+            // Rows that end in EOS take the EOS rule; everything else (parent already finished, leaf
+            // reached without an EOS id) is rescanned the general way, one wave per row.
+            __shared__ int s_pcode[MAXK];
+            __shared__ unsigned char s_rescan[MAXK];
+            // This call's plans sit where the next call's are about to be written: a workgroup reads and
+            // then overwrites its own K entries.  A call on one row per group has its B plans spread over
+            // entries that OTHER workgroups overwrite, so there the parents' nodes are not used and every
+            // row takes the general scan (first step of a search only).
+            for (int k = tid; k < K; k += BS_THREADS)
+                s_pcode[k] = a.cand_shared ? GRX_RES_EMPTY : plan_out[row0 + k].code;
+            __syncthreads();
+            for (int k = tid; k < K; k += BS_THREADS) {
+                const int j = s_run_idx[k];
+                const int tokv = s_tok[j], pcode = s_pcode[s_parent[j]];
+                grx_row_plan pl;
+                pl.code = GRX_RES_EMPTY;
+                bool known = false;
+                if (pc.eos >= 0 && tokv == pc.eos) {
+                    pl.code = GRX_RES_EOS;
+                    pl.off = 0;
+                    pl.n = 1;
+                    known = true;
+                } else if (pcode >= 0) {
+                    const int child = trie_child(pc.tv, pcode, (int64_t)tokv);
+                    if (child >= 0) {
+                        const int lo = pc.tv.off[child], hi = pc.tv.off[child + 1];
+                        if (hi > lo) {
+                            pl.code = child;
+                            pl.off = lo;
+                            pl.n = hi - lo;
+                            known = true;
+                        }
+                    }
+                }
+                pl.pad = 0;
+                s_rescan[k] = known ? 0 : 1;
+                if (known) plan_out[row0 + k] = pl;
+            }
+            __syncthreads();
+            for (int k = wave; k < K; k += BS_WAVES) {
+                if (!s_rescan[k]) continue;
+                const grx_row_plan pl = plan_fixed_row(pc, a.run_seq_out + (row0 + k) * L, T_next, lane);
+                if (lane == 0) plan_out[row0 + k] = pl;
+            }
+        }
+    }
+}

@@ -269,6 +269,8 @@ struct PlanCtx {
     int slot;             // state slot the planned call owns (count mode)
     int count_set;        // 1: the caller set the counter since the last call; it starts at count_value
     int count_value;
+    int count_ready;      // 1: count[slot] already holds the count this call starts with (whoever prepared the
+                          //    call recorded it), so nothing of the previous call's slot is read
     int prefix_index;
     int eos;
     TrieView tv;
@@ -278,6 +280,7 @@ struct PlanCtx {
 // Count-based mode (logit_processor.py:38-44).  The shared counter a call starts with is the
 // counter after the previous call, unless the caller set it in between.
 __device__ __forceinline__ int plan_start_count(const PlanCtx& c) {
+    if (c.count_ready) return c.st->count[c.slot];
     return c.count_set ? c.count_value : state_count_after(*c.st, (c.slot + 2) % 3);
 }
 

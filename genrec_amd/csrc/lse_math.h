@@ -70,23 +70,36 @@ __device__ __forceinline__ void fill_store(u32x4* p, const u32x4& v) {
 #endif
 }
 typedef int i32x2 __attribute__((ext_vector_type(2)));
+// Candidate stores.  COH = false: non-temporal, for rows the NEXT kernel reads.  COH = true: device-scope
+// (written through this XCD's L2), for rows that another workgroup of this same kernel reads once the
+// writer has waited for them (s_waitcnt vmcnt(0)) and counted itself in.
 // Two adjacent entries (16 bytes; p is 16-byte aligned).
+template <bool COH = false>
 __device__ __forceinline__ void cand_store2(grx_cand* p, const grx_cand& v0, const grx_cand& v1) {
     typedef int i32x4 __attribute__((ext_vector_type(4)));
     const i32x4 w = {v0.x, v0.y, v1.x, v1.y};
+    if constexpr (COH) {
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(w) : "memory");
+    } else {
 #if MLS_NTST
-    __builtin_nontemporal_store(w, reinterpret_cast<i32x4*>(p));
+        __builtin_nontemporal_store(w, reinterpret_cast<i32x4*>(p));
 #else
-    *reinterpret_cast<i32x4*>(p) = w;
+        *reinterpret_cast<i32x4*>(p) = w;
 #endif
+    }
 }
+template <bool COH = false>
 __device__ __forceinline__ void cand_store(grx_cand* p, const grx_cand& v) {
     const i32x2 w = {v.x, v.y};
+    if constexpr (COH) {
+        asm volatile("global_store_dwordx2 %0, %1, off sc1" : : "v"(p), "v"(w) : "memory");
+    } else {
 #if MLS_NTST
-    __builtin_nontemporal_store(w, reinterpret_cast<i32x2*>(p));
+        __builtin_nontemporal_store(w, reinterpret_cast<i32x2*>(p));
 #else
-    *reinterpret_cast<i32x2*>(p) = w;
+        *reinterpret_cast<i32x2*>(p) = w;
 #endif
+    }
 }
 
 // ---- element traits --------------------------------------------------------

@@ -7,6 +7,7 @@
 #include <hip/hip_ext.h>
 #include <hip/hip_fp16.h>
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -16,6 +17,15 @@
 #include "resolve.h"
 
 #include "lse_math.h"
+#ifdef FUSE_STAMP
+// Diagnostic build only: phase timestamps (100 MHz counter) of the beam steps that run inside the streaming kernel.
+__device__ unsigned long long g_fuse_stamps[1024 * 16];
+#define STAMP(n) do { if (tid == 0 && b < 1024) g_fuse_stamps[b * 16 + (n)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+extern "C" __attribute__((visibility("default"))) int grx_debug_read_fuse_stamps(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fuse_stamps), sizeof(unsigned long long) * 1024 * 16);
+}
+#endif
+#include "beam_body.h"
 
 enum { OUT_COMPACT = 0, OUT_FULL_F32 = 1, OUT_FULL_SAME = 2 };
 
@@ -96,7 +106,7 @@ extern "C" __attribute__((visibility("default"))) int grx_debug_read_mls_stamps(
 // order.  Lane l holds keys l, l + 64, ...: the keep-th largest key is built bit by bit from ballot
 // counts (32 rounds of Q compares, nothing leaves the registers), keys above it take the first slots
 // in candidate order, keys equal to it the remaining ones.
-template <int Q>
+template <int Q, bool COH>
 __device__ __forceinline__ void select_top(const uint32_t* s_key, const float* s_lp, const int32_t* __restrict__ toks,
                                            int n, int keep, int lane, grx_cand* __restrict__ crow) {
     uint32_t key[Q];
@@ -134,7 +144,7 @@ __device__ __forceinline__ void select_top(const uint32_t* s_key, const float* s
             grx_cand v;
             v.x = toks[i];
             v.y = __float_as_int(s_lp[i]);
-            cand_store(crow + 1 + pos, v);
+            cand_store<COH>(crow + 1 + pos, v);
         }
         gt_seen += __popcll(m_gt);
         eq_seen += __popcll(m_eq);
@@ -145,8 +155,25 @@ __device__ __forceinline__ void select_top(const uint32_t* s_key, const float* s
 // DT: element type of the logits.  OUT: OUT_*.  VEC: rows (and, for the full
 // modes, output rows) are 16-byte aligned so the stream uses 16-byte accesses;
 // otherwise one element per access.
-template <int DT, int OUT, bool VEC, bool SPLIT, bool PEN>
-__global__ __launch_bounds__(MLS_THREADS) void masked_lsm_kernel(MlsArgs a) {
+// FUSE (compact rows only): the workgroup that completes a prompt group -- the last of its K rows to be
+// emitted -- runs the group's beam step (`fb`) on the spot, while other groups still stream.
+struct FusedBeam {
+    grx_beam_step_args a;
+    BeamDerived d;
+    PlanCtx pc;              // the processor call AFTER this one, planned by the beam step
+    grx_row_plan* plan_out;
+};
+
+#ifndef MLS_ABL_COHSTORE
+#define MLS_ABL_COHSTORE 0  // diagnostic: 1 = the unfused kernel writes its candidate rows with device-scope stores too
+#endif
+#ifndef MLS_ABL_TAILWAIT
+#define MLS_ABL_TAILWAIT 0  // diagnostic: 1 = the unfused kernel ends every row like the fused one (store wait, barrier, atomic), 2 = without the store wait
+#endif
+
+template <int DT, int OUT, bool VEC, bool SPLIT, bool PEN, bool FUSE>
+__device__ __forceinline__ void mls_body(const MlsArgs& a, const FusedBeam* fb) {
+    constexpr bool COHST = FUSE || MLS_ABL_COHSTORE;
     typedef Elem<DT> E;
     typedef typename E::T T;
     constexpr int EPV = VEC ? E::kPerVec : 1;  // elements per access
@@ -662,24 +689,26 @@ __global__ __launch_bounds__(MLS_THREADS) void masked_lsm_kernel(MlsArgs a) {
                 }
             }
             __syncthreads();
-            if (tid >= GRX_WAVE) return;
-            const int lane = tid;
-            const int q_n = (c_n + GRX_WAVE - 1) / GRX_WAVE;
-            if (q_n <= 2) select_top<2>(s_key, s_lp, a.tok + c_off, c_n, keep, lane, crow);
-            else if (q_n <= 4) select_top<4>(s_key, s_lp, a.tok + c_off, c_n, keep, lane, crow);
-            else if (q_n <= 8) select_top<8>(s_key, s_lp, a.tok + c_off, c_n, keep, lane, crow);
-            else select_top<KPL>(s_key, s_lp, a.tok + c_off, c_n, keep, lane, crow);
-            const int n_kept_line = ((keep + 1 + 15) / 16) * 16;
-            if (lane == 0) {
-                grx_cand h;
-                h.x = keep;
-                h.y = __float_as_int(tot.m + log_s + lse2);
-                cand_store(crow, h);
+            if (!FUSE && !MLS_ABL_TAILWAIT && tid >= GRX_WAVE) return;
+            if (tid < GRX_WAVE) {
+                const int lane = tid;
+                const int q_n = (c_n + GRX_WAVE - 1) / GRX_WAVE;
+                if (q_n <= 2) select_top<2, COHST>(s_key, s_lp, a.tok + c_off, c_n, keep, lane, crow);
+                else if (q_n <= 4) select_top<4, COHST>(s_key, s_lp, a.tok + c_off, c_n, keep, lane, crow);
+                else if (q_n <= 8) select_top<8, COHST>(s_key, s_lp, a.tok + c_off, c_n, keep, lane, crow);
+                else select_top<KPL, COHST>(s_key, s_lp, a.tok + c_off, c_n, keep, lane, crow);
+                const int n_kept_line = ((keep + 1 + 15) / 16) * 16;
+                if (lane == 0) {
+                    grx_cand h;
+                    h.x = keep;
+                    h.y = __float_as_int(tot.m + log_s + lse2);
+                    cand_store<COHST>(crow, h);
+                }
+                const grx_cand zero = {0, 0};
+                for (int e = keep + 1 + lane; e < n_kept_line; e += GRX_WAVE) cand_store<COHST>(crow + e, zero);
             }
-            const grx_cand zero = {0, 0};
-            for (int e = keep + 1 + lane; e < n_kept_line; e += GRX_WAVE) cand_store(crow + e, zero);
-            return;
-        }
+            if (!FUSE && !MLS_ABL_TAILWAIT) return;
+        } else {
         auto entry = [&](int e, int tokv, float xm) {  // compact entry e of this row
             grx_cand v = {0, 0};
             if (e == 0) {
@@ -698,7 +727,7 @@ __global__ __launch_bounds__(MLS_THREADS) void masked_lsm_kernel(MlsArgs a) {
 #else
             if (e < n_line) {  // n_line is even, so the pair is inside the row
 #endif
-                cand_store2(crow + e, entry(e, e_tok[0], E::to_float(e_raw[0]) - tot.m), entry(e + 1, e_tok[1], E::to_float(e_raw[1]) - tot.m));
+                cand_store2<COHST>(crow + e, entry(e, e_tok[0], E::to_float(e_raw[0]) - tot.m), entry(e + 1, e_tok[1], E::to_float(e_raw[1]) - tot.m));
             }
         }
 #ifdef MLS_ABL_NOSTORE
@@ -710,7 +739,45 @@ __global__ __launch_bounds__(MLS_THREADS) void masked_lsm_kernel(MlsArgs a) {
             const int t0 = e - 1 < c_n ? a.tok[c_off + e - 1] : 0, t1 = e < c_n ? a.tok[c_off + e] : 0;
             const float x0 = e - 1 < c_n ? E::to_float(row[t0]) - tot.m : 0.f;
             const float x1 = e < c_n ? E::to_float(row[t1]) - tot.m : 0.f;
-            cand_store2(crow + e, entry(e, t0, x0), entry(e + 1, t1, x1));
+            cand_store2<COHST>(crow + e, entry(e, t0, x0), entry(e + 1, t1, x1));
+        }
+        }  // rows emitted whole
+#if MLS_ABL_TAILWAIT
+        if constexpr (!FUSE) {
+            __shared__ int s_dummy;
+            if (MLS_ABL_TAILWAIT == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                int* const arrivals = &const_cast<grx_row_plan*>(a.plan)[(int64_t)(r / 16) * 16].pad;
+                s_dummy = __hip_atomic_fetch_add(arrivals, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __syncthreads();
+            if (s_dummy == 12345) return;
+        }
+#endif
+        if constexpr (FUSE) {
+            // This row is done.  Its entries were written with device-scope stores; once every wave has
+            // seen its own stores complete, the workgroup counts itself into its prompt group -- the
+            // counter is the spare word of the plan entry of the group's first row, zero between calls --
+            // and the workgroup that completes the group runs its beam step right here, reading the K
+            // candidate rows with device-scope loads, while the rows of other groups still stream.
+            __shared__ int s_completes_group;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            const int K = fb->a.K;
+            const int g = r / K;
+            if (tid == 0) {
+                int* const arrivals = &const_cast<grx_row_plan*>(a.plan)[(int64_t)g * K].pad;
+                const int seen = __hip_atomic_fetch_add(arrivals, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (seen == K - 1) __hip_atomic_store(arrivals, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_completes_group = seen == K - 1;
+            }
+            __syncthreads();
+            if (!s_completes_group) return;
+#ifdef FUSE_ABL_NOTAIL
+            if (fb->a.V != -12345) return;  // diagnostic: the step is left to the beam kernel behind this one
+#endif
+            beam_step_group<BS_SMALL_K, BS_SMALL_KEEP, BS_SMALL_SURV, BS_SMALL_K, true>(fb->a, fb->d, fb->pc, fb->plan_out, g);
         }
     } else {
         OT* __restrict__ orow = reinterpret_cast<OT*>(a.out) + (int64_t)r * a.out_stride;
@@ -739,6 +806,18 @@ __global__ __launch_bounds__(MLS_THREADS) void masked_lsm_kernel(MlsArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     MSTAMP(6);
 #endif
+}
+
+template <int DT, int OUT, bool VEC, bool SPLIT, bool PEN>
+__global__ __launch_bounds__(MLS_THREADS) void masked_lsm_kernel(MlsArgs a) {
+    mls_body<DT, OUT, VEC, SPLIT, PEN, false>(a, nullptr);
+}
+
+// The step in one launch: compact candidates, and the beam step of every prompt group as soon as the
+// group's rows are complete.  16-byte aligned rows without repetition penalty only.
+template <int DT, bool SPLIT>
+__global__ __launch_bounds__(MLS_THREADS) void masked_lsm_beam_kernel(MlsArgs a, FusedBeam fb) {
+    mls_body<DT, OUT_COMPACT, true, SPLIT, false, true>(a, &fb);
 }
 
 // ---- dense output fill ---------------------------------------------------------
@@ -919,15 +998,61 @@ static void launch_dtype(int dtype, bool vec, const MlsArgs& a, hipStream_t stre
 
 static size_t dtype_size(int dt) { return dt == GRX_F32 ? 4 : 2; }
 
+template <int DT>
+static void launch_fused_split(const MlsArgs& a, const FusedBeam& fb, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
+    const dim3 grid((unsigned)a.R * (unsigned)(a.S > 1 ? a.S : 1));
+    if (a.S > 1) {
+        if (ev0 || ev1)
+            hipExtLaunchKernelGGL((masked_lsm_beam_kernel<DT, true>), grid, dim3(MLS_THREADS), 0, stream, ev0, ev1, 0, a, fb);
+        else
+            hipLaunchKernelGGL((masked_lsm_beam_kernel<DT, true>), grid, dim3(MLS_THREADS), 0, stream, a, fb);
+    } else {
+        if (ev0 || ev1)
+            hipExtLaunchKernelGGL((masked_lsm_beam_kernel<DT, false>), grid, dim3(MLS_THREADS), 0, stream, ev0, ev1, 0, a, fb);
+        else
+            hipLaunchKernelGGL((masked_lsm_beam_kernel<DT, false>), grid, dim3(MLS_THREADS), 0, stream, a, fb);
+    }
+}
+
+static void launch_fused(int dtype, const MlsArgs& a, const FusedBeam& fb, hipStream_t stream, hipEvent_t ev0,
+                         hipEvent_t ev1) {
+    if (dtype == GRX_F32) launch_fused_split<GRX_F32>(a, fb, stream, ev0, ev1);
+    else if (dtype == GRX_BF16) launch_fused_split<GRX_BF16>(a, fb, stream, ev0, ev1);
+    else launch_fused_split<GRX_F16>(a, fb, stream, ev0, ev1);
+}
+
 static bool rows_16b_aligned(const void* base, int64_t stride, size_t elsize) {
     return (((uintptr_t)base) & 15u) == 0 && ((stride * (int64_t)elsize) & 15) == 0;
 }
 
+// Largest launch whose beam steps run inside the streaming kernel.  A group's step holds a workgroup slot
+// for about 20 us, and the steps of the groups that finish last run after the stream has ended: with
+// thousands of rows that costs more than the separate beam kernel it replaces (8192 rows: 418 against
+// 385 us per step; 1024 rows: even), with few rows -- launch-bound steps -- it wins (64 rows: 45 against
+// 52 us).  GRX_FUSE_MAX_ROWS in the environment overrides the limit (tuning; read once).
+static int fuse_max_rows() {
+    static const int limit = [] {
+        const char* e = getenv("GRX_FUSE_MAX_ROWS");
+        return e != nullptr && *e ? atoi(e) : 512;
+    }();
+    return limit;
+}
+
+// `beam` (compact form only): the beam step that consumes the candidates, to be carried out by this same
+// call -- inside the streaming kernel where that is possible, by the beam kernel right behind it otherwise.
 static int run_step(const char* who, const grx_trie* trie, grx_state* state, const grx_rows* rows,
                     const grx_constraint* con, MlsArgs& a, int out_kind, bool out_aligned, void* workspace,
-                    size_t workspace_bytes, hipStream_t stream) {
+                    size_t workspace_bytes, hipStream_t stream, const grx_beam_step_args* beam = nullptr) {
     int rc = grx_check_step_args(who, trie, state, rows, con, workspace, workspace_bytes);
     if (rc != GRX_OK) return rc;
+    if (beam != nullptr) {
+        rc = grx_beam_step_check(who, beam);
+        if (rc != GRX_OK) return rc;
+        GRX_REQUIRE(beam->cand == a.cand && beam->cand_stride == a.cand_stride && beam->cmax == a.cmax, GRX_E_INVALID,
+                    "%s: the beam step must read the candidate buffer this call writes", who);
+        GRX_REQUIRE((int64_t)beam->B * (beam->cand_shared ? 1 : beam->K) == rows->R, GRX_E_INVALID,
+                    "%s: %d rows do not make %d groups of %d beams", who, rows->R, beam->B, beam->K);
+    }
     GRX_REQUIRE(con->eos_token_id < rows->V, GRX_E_INVALID, "%s: eos_token_id %d outside V=%d", who,
                 con->eos_token_id, rows->V);
     const bool penalise = con->repetition_penalty != 0.f && con->repetition_penalty != 1.f;
@@ -956,7 +1081,7 @@ static int run_step(const char* who, const grx_trie* trie, grx_state* state, con
                              : nullptr;
     rc = grx_plan_rows(trie, state, rows, con, plan, stream, &a.pc, &a.bookkeep);
     if (rc != GRX_OK) return rc;
-    if (rows->R == 0) return GRX_OK;
+    if (rows->R == 0) return GRX_OK;  // no rows, no groups: the beam step has nothing to do either
     a.walk = con->mode == GRX_MODE_COUNT ? 1 : 0;
     a.ids = rows->input_ids;
     a.ids_stride = rows->ids_stride;
@@ -1023,6 +1148,33 @@ static int run_step(const char* who, const grx_trie* trie, grx_state* state, con
         ev0 = nullptr;
 
     }
+    if (beam != nullptr) {
+        // One launch when the streaming kernel can carry the beam step: the 16-beam instantiation, one
+        // candidate row per beam, 16-byte aligned rows that are streamed, no penalty, and a call whose
+        // counter bookkeeping somebody else has done (a fused kernel must not read the state words of the
+        // previous call, which the plan it makes for the next call re-arms).
+        const bool fuse = vec && !a.skip_stream && a.penalty == 0.f && a.bookkeep == 0 && !beam->cand_shared &&
+                          grx_beam_step_is_small(*beam) && rows->R <= fuse_max_rows();
+        FusedBeam fb;
+        fb.a = *beam;
+        rc = grx_beam_step_derive(who, *beam, stream, &fb.d, &fb.pc, &fb.plan_out);
+        if (rc != GRX_OK) return rc;
+        if (fuse) {
+            if (con->mode == GRX_MODE_COUNT) a.pc.count_ready = 1;
+            launch_fused(rows->dtype, a, fb, stream, ev0, ev1);
+            GRX_CHECK_HIP(hipGetLastError());
+#ifdef FUSE_ABL_NOTAIL
+            grx_beam_step_launch(*beam, fb.d, fb.pc, fb.plan_out, stream);
+#endif
+        } else {
+            launch_dtype<OUT_COMPACT>(rows->dtype, vec, a, stream, ev0, ev1);
+            GRX_CHECK_HIP(hipGetLastError());
+            grx_beam_step_launch(*beam, fb.d, fb.pc, fb.plan_out, stream);
+            GRX_CHECK_HIP(hipGetLastError());
+        }
+        if (slot >= 0) g_timing_n = slot + 1;
+        return GRX_OK;
+    }
     if (out_kind == OUT_COMPACT) launch_dtype<OUT_COMPACT>(rows->dtype, vec, a, stream, ev0, ev1);
     else if (out_kind == OUT_FULL_F32) launch_dtype<OUT_FULL_F32>(rows->dtype, vec, a, stream, ev0, ev1);
     else launch_dtype<OUT_FULL_SAME>(rows->dtype, vec, a, stream, ev0, ev1);
@@ -1084,7 +1236,8 @@ extern "C" int64_t grx_candidate_stride(int32_t cmax) {
 
 static int candidates_call(const char* who, const grx_trie* trie, grx_state* state, const grx_rows* rows,
                            const grx_constraint* con, grx_cand* cand, int64_t cand_stride, int32_t cmax,
-                           void* workspace, size_t workspace_bytes, void* stream) {
+                           void* workspace, size_t workspace_bytes, void* stream,
+                           const grx_beam_step_args* beam = nullptr) {
     GRX_REQUIRE(rows != nullptr, GRX_E_INVALID, "%s: null rows", who);
     GRX_REQUIRE(cmax >= 1, GRX_E_INVALID, "%s: cmax must be >= 1", who);
     GRX_REQUIRE(cand_stride >= grx_candidate_stride(cmax) && cand_stride % 16 == 0, GRX_E_INVALID,
@@ -1097,7 +1250,16 @@ static int candidates_call(const char* who, const grx_trie* trie, grx_state* sta
     a.cand_stride = cand_stride;
     a.cmax = cmax;
     return run_step(who, trie, state, rows, con, a, OUT_COMPACT, true, workspace, workspace_bytes,
-                    (hipStream_t)stream);
+                    (hipStream_t)stream, beam);
+}
+
+extern "C" int grx_constrained_beam_step(const grx_trie* trie, grx_state* state, const grx_rows* rows,
+                                         const grx_constraint* con, grx_cand* cand, int64_t cand_stride, int32_t cmax,
+                                         void* workspace, size_t workspace_bytes, const grx_beam_step_args* beam,
+                                         void* stream) {
+    const char* who = "grx_constrained_beam_step";
+    GRX_REQUIRE(beam != nullptr, GRX_E_INVALID, "%s: null beam step arguments", who);
+    return candidates_call(who, trie, state, rows, con, cand, cand_stride, cmax, workspace, workspace_bytes, stream, beam);
 }
 
 extern "C" int grx_constrained_candidates(const grx_trie* trie, grx_state* state, const grx_rows* rows,

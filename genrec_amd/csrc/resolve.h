@@ -18,6 +18,8 @@ int grx_plan_rows(const grx_trie* trie, grx_state* state, const grx_rows* rows, 
 int grx_plan_ctx_for_next_call(const char* who, const grx_plan_request* req, int32_t n_rows, PlanCtx* ctx,
                                grx_row_plan** plan,
                                hipStream_t stream);
+// The argument checks of the above on their own (no state is touched).
+int grx_plan_request_check(const char* who, const grx_plan_request* req, int32_t n_rows);
 // Plan `R` rows of `T` tokens for the next call with the stand-alone planning kernel (no call counting).
 int grx_launch_plan_kernel(const PlanCtx& ctx, const int64_t* ids, int64_t ids_stride, int R, int T,
                            grx_row_plan* plan, hipStream_t stream);
@@ -40,3 +42,12 @@ int grx_split_factor(int R, int row_vecs);
 
 // Device view of a trie handle for kernel arguments.
 TrieView grx_trie_view(const grx_trie* trie);
+
+// Beam step pieces shared with the streaming kernel's fused form (beam_step.hip).
+struct BeamDerived;
+int grx_beam_step_check(const char* who, const grx_beam_step_args* args);
+bool grx_beam_step_is_small(const grx_beam_step_args& a);
+int grx_beam_step_derive(const char* who, const grx_beam_step_args& a, hipStream_t stream, BeamDerived* d_out, PlanCtx* pc,
+                         grx_row_plan** plan_out);
+void grx_beam_step_launch(const grx_beam_step_args& a, const BeamDerived& d, const PlanCtx& pc, grx_row_plan* plan_out,
+                          hipStream_t stream);

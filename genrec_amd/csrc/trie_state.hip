@@ -333,8 +333,7 @@ int grx_plan_rows(const grx_trie* trie, grx_state* state, const grx_rows* rows, 
     return grx_launch_plan_kernel(ctx, rows->input_ids, rows->ids_stride, rows->R, rows->T, plan, stream);
 }
 
-int grx_plan_ctx_for_next_call(const char* who, const grx_plan_request* req, int32_t n_rows, PlanCtx* ctx,
-                               grx_row_plan** plan, hipStream_t stream) {
+int grx_plan_request_check(const char* who, const grx_plan_request* req, int32_t n_rows) {
     GRX_REQUIRE(req->trie && req->con, GRX_E_INVALID, "%s: plan request without trie / constraint", who);
     GRX_REQUIRE(req->con->mode == GRX_MODE_COUNT || req->con->mode == GRX_MODE_FIXED_HINT, GRX_E_INVALID,
                 "%s: plan request with bad mode %d", who, req->con->mode);
@@ -346,6 +345,13 @@ int grx_plan_ctx_for_next_call(const char* who, const grx_plan_request* req, int
                     req->workspace_bytes >= grx_workspace_bytes(n_rows),
                 GRX_E_WORKSPACE, "%s: plan request needs a 16-byte aligned workspace of %zu bytes", who,
                 grx_workspace_bytes(n_rows));
+    return GRX_OK;
+}
+
+int grx_plan_ctx_for_next_call(const char* who, const grx_plan_request* req, int32_t n_rows, PlanCtx* ctx,
+                               grx_row_plan** plan, hipStream_t stream) {
+    const int rc = grx_plan_request_check(who, req, n_rows);
+    if (rc != GRX_OK) return rc;
     const int slot = req->con->mode == GRX_MODE_COUNT ? (int)(req->state->calls % 3u) : 0;
     if (req->con->mode == GRX_MODE_COUNT) {
         if (req->state->ahead_open) {  // the plan made ahead before this one was never used

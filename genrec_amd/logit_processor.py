@@ -502,7 +502,7 @@ class _TrieConstrainedBase(LogitsProcessor):
         return min(width, keep + self.KEEP_TOP_SLACK) if keep else width
 
     def candidates_into(self, input_ids, scores, cand: "Candidates", one_row_per_group: bool = False,
-                        keep_top: int = 0, row_bias: Optional[torch.Tensor] = None) -> None:
+                        keep_top: int = 0, row_bias: Optional[torch.Tensor] = None, beam_step=None) -> None:
         """``candidates`` writing into a caller-owned buffer (no allocation per step).
 
         ``keep_top`` > 0: rows with more than ``keep_top + KEEP_TOP_SLACK`` allowed tokens emit only their
@@ -513,7 +513,11 @@ class _TrieConstrainedBase(LogitsProcessor):
         ``one_row_per_group``: the rows are prompts, one per beam group, instead of ``num_beams``
         identical copies of each (the first step of a search: the copies would give identical
         results, see ``BeamSearchState.step(..., shared_rows=True)``).  The shared counter moves
-        exactly as for the full batch."""
+        exactly as for the full batch.
+
+        ``beam_step`` (a filled ``GrxBeamStepArgs`` that reads ``cand``; see ``BeamSearchState.fused_step``):
+        the beam step that consumes the candidates is carried out by this same library call
+        (``grx_constrained_beam_step``) -- inside the streaming kernel where the library can."""
         rows, ids_keep, scores_keep = self._rows(input_ids, scores, whole_groups=not one_row_per_group)
         index = self._device_index(scores_keep)
         assert cand.rows == rows.R and cand.buf.device == scores_keep.device
@@ -528,20 +532,29 @@ class _TrieConstrainedBase(LogitsProcessor):
             con = self._constraint()
             con.keep_top = int(keep_top)
             con.row_bias = row_bias.data_ptr() if (row_bias is not None and keep_top) else None
-            _lib.check(
-                _lib.lib().grx_constrained_candidates(
-                    self.trie.device_handle(scores_keep.device),
-                    st.ptr,
-                    C.byref(rows),
-                    C.byref(con),
-                    cand.buf.data_ptr(),
-                    cand.stride,
-                    cand.cmax,
-                    ws.data_ptr(),
-                    ws.numel(),
-                    _lib.current_stream_ptr(scores_keep.device),
+            if beam_step is not None:
+                _lib.check(
+                    _lib.lib().grx_constrained_beam_step(
+                        self.trie.device_handle(scores_keep.device), st.ptr, C.byref(rows), C.byref(con),
+                        cand.buf.data_ptr(), cand.stride, cand.cmax, ws.data_ptr(), ws.numel(), C.byref(beam_step),
+                        _lib.current_stream_ptr(scores_keep.device),
+                    )
                 )
-            )
+            else:
+                _lib.check(
+                    _lib.lib().grx_constrained_candidates(
+                        self.trie.device_handle(scores_keep.device),
+                        st.ptr,
+                        C.byref(rows),
+                        C.byref(con),
+                        cand.buf.data_ptr(),
+                        cand.stride,
+                        cand.cmax,
+                        ws.data_ptr(),
+                        ws.numel(),
+                        _lib.current_stream_ptr(scores_keep.device),
+                    )
+                )
         self._active = index
         if self.sync_errors:
             self.check_errors()

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define GRX_ABI_VERSION 12
+#define GRX_ABI_VERSION 13
 
 #if defined(GRX_BUILDING)
 #define GRX_API __attribute__((visibility("default")))
@@ -461,6 +461,28 @@ typedef struct grx_beam_init_args {
 } grx_beam_init_args;
 
 GRX_API int grx_beam_init(const grx_beam_init_args* args, void* stream);
+
+/*
+ * A whole decode step in one call: grx_constrained_candidates(trie, state, rows, con, cand, ...)
+ * followed by grx_beam_step(beam) on those candidates -- the loop body of _beam_search
+ * (generation/utils.py:3384-3508 of transformers 5.15.0) that the reference enters from
+ * MIMIGenRec.py:79 and evaluate.py:363-371, with logit_processor.py:29-49 inside it.  Same
+ * arguments, same results and same side effects (counter, row errors, the plan made for the next
+ * call) as the two calls in that order; beam->cand, beam->cand_stride and beam->cmax must be the
+ * candidate buffer given here, and rows->R == beam->B * beam->K (beam->B with cand_shared).
+ * Where it can, the call is ONE launch: the workgroup that emits the last candidate row of a
+ * prompt group carries out that group's beam step on the spot, while the rows of other groups are
+ * still being streamed, so only the last groups' steps add to the kernel's duration.  That form
+ * serves searches of at most 16 beams that keep at most 64 candidates, 16-byte aligned logit rows,
+ * no repetition penalty, no assume_normalized, no cand_shared, and count-based calls that arrive
+ * planned (grx_rows.planned = 1) or carry prefix_ids; anything else runs the two kernels back to
+ * back.  The workspace must be the one whose plan entries this state's calls use (zero-filled when
+ * first handed over): the spare word of a group's first plan entry counts the group's finished rows.
+ */
+GRX_API int grx_constrained_beam_step(const grx_trie* trie, grx_state* state, const grx_rows* rows,
+                                      const grx_constraint* con, grx_cand* cand, int64_t cand_stride, int32_t cmax,
+                                      void* workspace, size_t workspace_bytes, const grx_beam_step_args* beam,
+                                      void* stream);
 
 /* ----------------------------------------------------------------- scoring --- */
 
