@@ -458,6 +458,10 @@ def main() -> None:
                     help="let every processor call run its own row planning kernel (as under the plain HF loop)")
     ap.add_argument("--no-keep-top", action="store_true",
                     help="rows emit every allowed token instead of their 2 x beams best (A/B of the row truncation)")
+    ap.add_argument("--graph", action="store_true",
+                    help="record three generations (3 x depth steps with their scoring and re-initialisation) as one HIP "
+                         "graph and replay it: the host leaves the loop (small launches are host-bound); whole replays "
+                         "only, the remainder of --steps runs eagerly; no per-kernel events (roofline.kernel_ms null)")
     ap.add_argument("--no-fused-step", action="store_true",
                     help="processor call and beam step as two library calls (two kernels) instead of one (A/B)")
     ap.add_argument("--lazy-turnover", action="store_true",
@@ -565,11 +569,30 @@ def main() -> None:
     torch.cuda.synchronize()
     barrier()
     lib = _lib.lib()
-    lib.grx_timing_enable(0 if args.no_kernel_timing else max(1, args.time_every))
+    captured, per_replay = None, 3 * wl["levels"]
+    if args.graph:
+        from genrec_amd.graph import capture
+
+        def three_generations():
+            for _ in range(per_replay):
+                roll.step()
+
+        captured = capture(three_generations, [wl["proc"]])
+        for _ in range(3):
+            captured.replay()
+        torch.cuda.synchronize()
+        barrier()
+    lib.grx_timing_enable(0 if (args.no_kernel_timing or args.graph) else max(1, args.time_every))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        roll.step()
+    if captured is not None:
+        for _ in range(args.steps // per_replay):
+            captured.replay()
+        for _ in range(args.steps % per_replay):
+            roll.step()
+    else:
+        for _ in range(args.steps):
+            roll.step()
     roll.finish()
     torch.cuda.synchronize()
     barrier()
@@ -589,9 +612,9 @@ def main() -> None:
     if rank == 0:
         R = args.batch * args.beams
         esize = 4 if args.dtype == "fp32" else 2
-        kernel_ms = tot.value / n.value if n.value else float("nan")
+        kernel_ms = tot.value / n.value if n.value else None
         alg_bytes = R * wl["V"] * esize
-        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms else None
         traffic, traffic_source = recorded_traffic(args, alg_bytes)
         probe = time_read_probe(wl, device)
         out = {
@@ -630,7 +653,7 @@ def main() -> None:
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
+                "frac": achieved / HBM_PEAK_GBS if achieved else None,
                 # the same bytes over the whole step (everything `value` pays for), slowest rank
                 "step_frac": alg_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
                 "traffic": traffic,
@@ -643,7 +666,8 @@ def main() -> None:
                 "read_probe": probe,
                 "settle": settled,
                 "untimed_steps_before_region": ramp + args.warmup,
-                "frac_of_read_probe": achieved / probe["GBps"] if probe["GBps"] else None,
+                "frac_of_read_probe": achieved / probe["GBps"] if (achieved and probe["GBps"]) else None,
+                "hip_graph": bool(args.graph),
             },
         }
         if world == 1 and not args.no_processor_surface:

@@ -29,12 +29,11 @@ int grx_check_step_args(const char* who, const grx_trie* trie, const grx_state* 
                         const grx_constraint* con, const void* workspace, size_t workspace_bytes, int32_t vocab = -1);
 
 // Split rows.  With few rows, one workgroup per row leaves most of the chip idle,
-// so a row is streamed by S workgroups (S a power of two, R * S <= GRX_SPLIT_MAX_PARTS).
-// The merge costs about 10 us of device-scope atomics, which only pays below a few
-// hundred rows (measured: 256 rows 25.8 -> 19.6 us, 16 rows 23.6 -> 14.7 us, 512 rows slower).
+// so a row is streamed by S workgroups (S a power of two, see grx_split_factor) whose partial
+// (max, sum) pairs the last one to arrive merges through device-scope atomics.
 // The caller's workspace holds the arrival counters ([GRX_SPLIT_MAX_ROWS] int32, zero
 // between calls) followed by the partial (max, sum) pairs; the row plans come after them.
-#define GRX_SPLIT_MAX_ROWS 256
+#define GRX_SPLIT_MAX_ROWS 1024
 #define GRX_SPLIT_MAX_PARTS 2048
 #define GRX_SPLIT_COUNT_BYTES (GRX_SPLIT_MAX_ROWS * 4)
 #define GRX_WS_PLAN_OFFSET (GRX_SPLIT_COUNT_BYTES + GRX_SPLIT_MAX_PARTS * 8)

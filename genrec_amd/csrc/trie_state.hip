@@ -233,12 +233,19 @@ extern "C" size_t grx_workspace_bytes(int32_t R) {
     return GRX_WS_PLAN_OFFSET + rows * sizeof(grx_row_plan);
 }
 
-// Number of workgroups that share one row: enough to fill the 256 CUs eight deep,
-// while every thread still streams at least two 16-byte vectors.
+// Number of workgroups that share one row.  Launches this small are latency-bound: what counts is
+// that all workgroups are resident at once (a second round of workgroups waits for the first to end:
+// 64 rows x 32 parts = 2048 workgroups took 37.6 us, 64 x 8 = 512 take 26.4 us) while every part still
+// streams at least two batches of loads.  Up to 256 rows: at most 512 workgroups; 257 .. 512 rows: two
+// parts per row (400 rows: 34.8 -> 32.2 us).  GRX_SPLIT_ROWS / GRX_SPLIT_TARGET in the environment
+// override the two limits (tuning; read once).
 int grx_split_factor(int R, int row_vecs) {
-    if (R <= 0 || R > GRX_SPLIT_MAX_ROWS) return 1;
+    static const int max_rows = [] { const char* e = getenv("GRX_SPLIT_ROWS"); return e && *e ? atoi(e) : 512; }();
+    static const int target = [] { const char* e = getenv("GRX_SPLIT_TARGET"); return e && *e ? atoi(e) : 0; }();
+    if (R <= 0 || R > GRX_SPLIT_MAX_ROWS || R > max_rows) return 1;
+    const int limit = target > 0 ? target : (R <= 256 ? 512 : 1024);
     int S = 1;
-    while (S < 32 && R * (S * 2) <= GRX_SPLIT_MAX_PARTS && row_vecs / (S * 2) >= 512) S *= 2;
+    while (S < 32 && R * (S * 2) <= GRX_SPLIT_MAX_PARTS && R * (S * 2) <= limit && row_vecs / (S * 2) >= 512) S *= 2;
     return S;
 }
 

@@ -72,7 +72,7 @@ def test_streamed_rows_with_penalty_match_the_float64_chain(V, dtype, kind, hist
     from genrec_amd.trie import FlatTrie, create_prefix_allowed_tokens_fn
 
     dev = _dev()
-    rows = 320  # above the split-row limit: one workgroup streams a row from end to end
+    rows = 640  # above the split-row limit: one workgroup streams a row from end to end
     seqs, first = _trie(V, 90, seed=V % 1000)
     fn = create_prefix_allowed_tokens_fn(FlatTrie(seqs), [11, 12, 13])
     rng = np.random.default_rng(hist_len + V)

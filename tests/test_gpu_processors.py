@@ -338,15 +338,15 @@ def test_few_rows_are_split_across_workgroups_with_the_same_results(dtype):
     fn = create_prefix_allowed_tokens_fn(trie, suffix)
     V, K = tok.vocab_size_padded, 16
     proc = ConstrainedLogitsProcessor(fn, K, pidx, None, tok.eos_token_id, sync_errors=True)
-    big_ids = torch.from_numpy(sample_decode_rows(trie, 32, K, 2, seed=9)).to(dev)      # 512 rows: not split
+    big_ids = torch.from_numpy(sample_decode_rows(trie, 40, K, 2, seed=9)).to(dev)      # 640 rows: not split
     torch.manual_seed(11)
-    big = (torch.randn(512, V, device=dev) * 4).to(dtype)
+    big = (torch.randn(640, V, device=dev) * 4).to(dtype)
     big[3, 17] = 60.0  # a dominant logit far from the row's allowed tokens
     proc.count = 2
     want = proc.candidates(big_ids, big)
     exact = torch.logsumexp(big.double(), dim=-1)
     assert float((want.logsumexp.double() - exact).abs().max()) <= FP32_TOL
-    for R in (256, 16, 64, 16):  # descending and ascending: the shared scratch is left clean every time
+    for R in (512, 256, 16, 64, 400, 16):  # descending and ascending: the shared scratch is left clean every time
         proc.count = 2
         got = proc.candidates(big_ids[:R], big[:R])
         assert torch.equal(got.count, want.count[:R])
