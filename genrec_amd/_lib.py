@@ -40,6 +40,8 @@ EXPORTED_SYMBOLS = (
     "grx_constrained_logsoftmax_reuse",
     "grx_constrained_candidates",
     "grx_constrained_beam_step",
+    "grx_lm_head_scratch_bytes",
+    "grx_lm_head_candidates",
     "grx_candidate_stride",
     "grx_noalloc_max_rows",
     "grx_constrained_candidates_noalloc",
@@ -93,6 +95,17 @@ class GrxConstraint(C.Structure):
         ("assume_normalized", C.c_int32),
         ("keep_top", C.c_int32),
         ("row_bias", C.c_void_p),
+    ]
+
+
+class GrxLmHead(C.Structure):
+    _fields_ = [
+        ("hidden", C.c_void_p),
+        ("hidden_stride", C.c_int64),
+        ("weight", C.c_void_p),
+        ("weight_stride", C.c_int64),
+        ("H", C.c_int32),
+        ("reserved", C.c_int32),
     ]
 
 
@@ -265,6 +278,13 @@ def _declare(lib: C.CDLL) -> None:
     lib.grx_constrained_beam_step.restype = C.c_int
     lib.grx_constrained_beam_step.argtypes = [
         vp, vp, C.POINTER(GrxRows), C.POINTER(GrxConstraint), vp, i64, i32, vp, C.c_size_t, C.POINTER(GrxBeamStepArgs), vp,
+    ]
+    lib.grx_lm_head_scratch_bytes.restype = C.c_size_t
+    lib.grx_lm_head_scratch_bytes.argtypes = [vp, i32, i32]
+    lib.grx_lm_head_candidates.restype = C.c_int
+    lib.grx_lm_head_candidates.argtypes = [
+        vp, vp, C.POINTER(GrxRows), C.POINTER(GrxConstraint), C.POINTER(GrxLmHead), vp, C.c_size_t, vp, i64, i32, vp,
+        C.c_size_t, vp,
     ]
     lib.grx_noalloc_max_rows.restype = i32
     lib.grx_noalloc_max_rows.argtypes = []

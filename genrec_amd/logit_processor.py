@@ -559,6 +559,67 @@ class _TrieConstrainedBase(LogitsProcessor):
         if self.sync_errors:
             self.check_errors()
 
+    def lm_head_candidates_into(self, input_ids, hidden: torch.Tensor, weight: torch.Tensor, cand: "Candidates",
+                                one_row_per_group: bool = False) -> None:
+        """``candidates_into`` for logits that are never written out: ``hidden`` [rows, H] and ``weight``
+        [vocab, H] (the output projection's ``nn.Linear.weight``; both bf16) are multiplied tile by tile
+        on the matrix cores inside the call (``grx_lm_head_candidates``), and only per-tile (max, sum-of-exp)
+        pairs plus the logits of the vocabulary's top columns -- where the trie's tokens live -- leave the
+        multiplication.  Same candidate rows as ``candidates_into(input_ids, (hidden @ weight.T).float(), cand)``
+        up to fp32 summation order.  No repetition penalty, ``assume_normalized`` or ``keep_top`` in this form."""
+        _lib.require_cuda(hidden, "hidden")
+        _lib.require_cuda(weight, "weight")
+        if hidden.dim() != 2 or weight.dim() != 2 or hidden.shape[1] != weight.shape[1]:
+            raise ValueError("hidden must be [rows, H] and weight [vocab, H]")
+        if hidden.dtype != torch.bfloat16 or weight.dtype != torch.bfloat16:
+            raise TypeError("the fused LM head takes bfloat16 hidden states and weights")
+        if hidden.stride(1) != 1:
+            hidden = hidden.contiguous()
+        if weight.stride(1) != 1:
+            weight = weight.contiguous()
+        if input_ids.shape[0] != hidden.shape[0]:
+            raise ValueError(f"hidden must have one row per sequence ({input_ids.shape[0]}); got {hidden.shape[0]}")
+        assert input_ids.dim() == 2, "input_ids must be a 2D tensor"
+        _lib.require_cuda(input_ids, "input_ids")
+        if not one_row_per_group and input_ids.shape[0] % self._num_beams != 0:
+            raise RuntimeError(
+                f"shape '[-1, {self._num_beams}, {input_ids.shape[1]}]' is invalid for input of size {input_ids.numel()}")
+        if input_ids.dtype != torch.int64:
+            input_ids = input_ids.to(torch.int64)
+        if input_ids.shape[1] > 0 and input_ids.stride(1) != 1:
+            input_ids = input_ids.contiguous()
+        rows = _lib.GrxRows()
+        rows.input_ids = input_ids.data_ptr()
+        rows.ids_stride = input_ids.stride(0) if input_ids.shape[0] > 1 else max(input_ids.shape[1], 1)
+        rows.R, rows.T = input_ids.shape[0], input_ids.shape[1]
+        rows.V = weight.shape[0]
+        rows.scores_stride = weight.shape[0]
+        rows.dtype = _lib.GRX_BF16
+        index = self._device_index(hidden)
+        assert cand.rows == rows.R and cand.buf.device == hidden.device
+        head = _lib.GrxLmHead()
+        head.hidden, head.hidden_stride = hidden.data_ptr(), hidden.stride(0) if hidden.shape[0] > 1 else hidden.shape[1]
+        head.weight, head.weight_stride = weight.data_ptr(), weight.stride(0)
+        head.H = hidden.shape[1]
+        self._take_planned(rows, input_ids)
+        with torch.cuda.device(index):
+            st = self._state(index)
+            ws = self._workspace(index, rows.R)
+            con = self._constraint()
+            handle = self.trie.device_handle(hidden.device)
+            need = int(_lib.lib().grx_lm_head_scratch_bytes(handle, rows.R, rows.V))
+            scratch = self._partials(index, (need + 3) // 4)
+            _lib.check(
+                _lib.lib().grx_lm_head_candidates(
+                    handle, st.ptr, C.byref(rows), C.byref(con), C.byref(head), scratch.data_ptr(), scratch.numel() * 4,
+                    cand.buf.data_ptr(), cand.stride, cand.cmax, ws.data_ptr(), ws.numel(),
+                    _lib.current_stream_ptr(hidden.device),
+                )
+            )
+        self._active = index
+        if self.sync_errors:
+            self.check_errors()
+
     def chunked_step(self, input_ids, cand: "Candidates", v_total: int, bounds, dtype,
                      one_row_per_group: bool = False, parts: Optional[int] = None) -> "ChunkedStep":
         """``candidates_into`` for logits that arrive as column slices of the vocabulary (the LM head

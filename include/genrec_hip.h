@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define GRX_ABI_VERSION 13
+#define GRX_ABI_VERSION 14
 
 #if defined(GRX_BUILDING)
 #define GRX_API __attribute__((visibility("default")))
@@ -316,6 +316,38 @@ GRX_API int grx_constrained_finish_penalised(const grx_rows* rows, const grx_con
                                              int32_t n_slots, const float* partials, const float* pen_logits,
                                              int64_t pen_stride, grx_cand* cand, int64_t cand_stride, int32_t cmax,
                                              const void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * The LM head inside the step (no counterpart in the reference, where the model's forward pass
+ * writes the whole [R, V] logits tensor -- MIMIGenRec.py:79, evaluate.py:363-371 -- and
+ * logit_processor.py:30 reads it back): logits = hidden [R, H] x weight^T, weight being the
+ * [V, H] matrix of the output projection (nn.Linear.weight), are formed tile by tile on the matrix
+ * cores (bf16 operands, fp32 accumulation) and consumed on the spot.  Per row and 256-column tile
+ * only a (max, sum-of-exp) pair leaves the multiplication, plus the fp32 logits of the column
+ * tiles at the top of the vocabulary that hold the trie's tokens (token ids 151,665 + rank for
+ * semantic-ID tokens: at most the last 4096 columns are kept; a trie token below them gets its
+ * logit from a dot product in the finishing kernel).  The result is the candidate rows
+ * grx_constrained_candidates would emit for scores = fp32(hidden x weight^T): same tokens, same
+ * order, log-probabilities equal up to fp32 summation order.  rows->scores is ignored,
+ * rows->V is the vocabulary width, rows->dtype must be GRX_BF16 (the operands' type); H must be a
+ * multiple of 64 and operand rows 16-byte aligned.  scratch: device buffer of
+ * grx_lm_head_scratch_bytes(trie, R, V) bytes, contents need no initialisation.  Not available
+ * with the fused repetition penalty, assume_normalized or keep_top.  Counter, row errors and
+ * plans made ahead behave as in grx_constrained_candidates.
+ */
+typedef struct grx_lm_head {
+    const void* hidden;     /* device bf16 [R, H], row stride hidden_stride (elements)       */
+    int64_t hidden_stride;
+    const void* weight;     /* device bf16 [V, H], row stride weight_stride (elements)       */
+    int64_t weight_stride;
+    int32_t H;
+    int32_t reserved;
+} grx_lm_head;
+GRX_API size_t grx_lm_head_scratch_bytes(const grx_trie* trie, int32_t R, int32_t V);
+GRX_API int grx_lm_head_candidates(const grx_trie* trie, grx_state* state, const grx_rows* rows,
+                                   const grx_constraint* con, const grx_lm_head* head, void* scratch,
+                                   size_t scratch_bytes, grx_cand* cand, int64_t cand_stride, int32_t cmax,
+                                   void* workspace, size_t workspace_bytes, void* stream);
 
 /*
  * Kernel timing for benchmarks (no counterpart in the reference).  While

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.lib()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.grx_abi_version() == 13
+    assert lib.grx_abi_version() == 14
     assert lib.grx_candidate_stride(162) == 176 and lib.grx_candidate_stride(1) == 16
     assert lib.grx_workspace_bytes(8192) >= 0
     # argument validation happens before any device work

@@ -4,7 +4,7 @@
 set -e
 cd "$(dirname "$0")/.."
 mkdir -p build/variants
-SRC="genrec_amd/csrc/trie_state.hip genrec_amd/csrc/masked_logsoftmax.hip genrec_amd/csrc/chunked_lse.hip genrec_amd/csrc/beam_step.hip genrec_amd/csrc/scoring.hip genrec_amd/csrc/exchange.hip"
+SRC="genrec_amd/csrc/trie_state.hip genrec_amd/csrc/masked_logsoftmax.hip genrec_amd/csrc/chunked_lse.hip genrec_amd/csrc/beam_step.hip genrec_amd/csrc/scoring.hip genrec_amd/csrc/exchange.hip genrec_amd/csrc/lm_head.hip"
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Iinclude -Igenrec_amd/csrc -fvisibility=hidden -DGRX_BUILDING -shared"
 while [ $# -ge 2 ]; do
   /opt/rocm/bin/hipcc $FLAGS $2 $SRC -o build/variants/lib_$1.so &
