@@ -21,10 +21,14 @@
 // 2 (vocabulary) x 4 (rows): 128 x 64 per wave = 4 x 2 accumulator tiles of 32 x 32.
 // K runs in steps of 64: the two operand tiles (256 x 64 bf16 = 32 KB each) are copied global -> LDS by
 // the DMA path (16 bytes per lane) into one of two buffers while the other one is being multiplied.
-// (Measured against this: a ring of four 32-deep steps with counted waits and raw barriers, with and
-// without fragment double-buffering in registers, and a persistent tile loop that prefetches the next
-// tile under the reduction -- all 3 to 8 % slower; one barrier per 64-deep step and no more than ~180
-// registers is what this structure wants.)
+// Measured against this structure at 8192 x 152,640 x 2048 (4.49 ms): a ring of four 32-deep steps with
+// counted waits and raw barriers (4.98 ms; 4.86 with fragment double-buffering in registers), a persistent
+// tile loop that prefetches the next tile's first step under the reduction (4.68 ms, 256 registers), and
+// four waves of 128 x 128 with one wave per SIMD and the accumulators in the AGPR half of the file, the
+// library kernel's geometry (5.48 ms: nothing hides a lone wave's LDS latency in compiler-scheduled code).
+// Counters of this kernel against the library's (rocprofv3 --pmc, same product): equal matrix-pipe busy
+// cycles, no LDS bank conflicts (library: 318 M), but 35 % of its wave cycles parked at the barrier /
+// its DMA wait against the library's 9 %.
 #define LH_THREADS 512
 #define LH_BM 256   // vocabulary entries per tile
 #define LH_BN 256   // rows per tile

@@ -99,6 +99,41 @@ class SlicedLMHead:
         call.finish()
 
 
+class FusedLMHead:
+    """The LM head multiplied inside the processor call (``grx_lm_head_candidates``): logits are formed tile
+    by tile on the matrix cores and reduced on the spot; nothing of shape [rows, vocab] exists.  ``head`` is a
+    plain ``torch.nn.Linear`` without bias, bf16, with a hidden size that is a multiple of 64.  No repetition
+    penalty and no row cut in this form."""
+
+    def __init__(self, head: torch.nn.Linear):
+        if type(head) is not torch.nn.Linear or head.bias is not None:
+            raise TypeError("the fused LM head needs a plain torch.nn.Linear output embedding without bias")
+        if head.weight.dtype != torch.bfloat16 or head.weight.shape[1] % 64:
+            raise TypeError("the fused LM head needs bfloat16 weights and a hidden size that is a multiple of 64")
+        self.weight = head.weight
+        self.V = self.weight.shape[0]
+
+    def candidates_into(self, processor, input_ids: torch.Tensor, hidden: torch.Tensor, cand,
+                        one_row_per_group: bool = False) -> None:
+        processor.lm_head_candidates_into(input_ids, hidden, self.weight, cand, one_row_per_group=one_row_per_group)
+
+
+def _model_body(model):
+    """The transformer without its LM head: what returns ``last_hidden_state``.  ``base_model_prefix`` names it
+    on the model that owns the head (``model.base_model`` of a PEFT wrapper is the adapter wrapper instead)."""
+    inner = model
+    for _ in range(4):  # through wrappers that merely hold the causal LM (peft: .base_model.model)
+        prefix = getattr(inner, "base_model_prefix", None)
+        if prefix and hasattr(inner, prefix) and getattr(inner, prefix) is not inner:
+            return getattr(inner, prefix)
+        nxt = getattr(getattr(inner, "base_model", None), "model", None)
+        if nxt is None or nxt is inner:
+            break
+        inner = nxt
+    raise TypeError("cannot find the transformer body of this model (no base_model_prefix attribute): the sliced / "
+                    "fused LM head needs the last hidden state")
+
+
 def reorder_generated_suffix(cache, beam_idx: torch.Tensor, prompt_len: int) -> None:
     """KV-cache re-ordering for beams that share their prompt.
 
@@ -146,6 +181,7 @@ def constrained_generate(
     share_prefill: bool = True,
     lm_head_slice: Optional[int] = None,
     lm_head_overlap: bool = False,
+    lm_head: Optional[str] = None,
 ) -> ConstrainedBeamOutput:
     """``input_ids`` [B, T] (left-padded like the reference's batches) on the model's device.
 
@@ -155,7 +191,13 @@ def constrained_generate(
     condition.  ``share_prefill=False`` prefills all K copies like ``generate()`` does.
     ``lm_head_slice`` (columns): run the LM head slice by slice through :class:`SlicedLMHead` instead
     of materialising [rows, vocab] logits (the fused repetition penalty works there too).
+    ``lm_head="fused"``: the LM head is multiplied inside the processor call (:class:`FusedLMHead`; bf16 model,
+    no repetition penalty): no logits tensor at all.
     """
+    if lm_head not in (None, "fused"):
+        raise ValueError(f'lm_head must be None or "fused", got {lm_head!r}')
+    if lm_head and lm_head_slice:
+        raise ValueError("choose one of lm_head_slice and lm_head")
     B, T = input_ids.shape
     K = int(num_beams)
     dev = input_ids.device
@@ -175,7 +217,7 @@ def constrained_generate(
                             shared_prompt=True, planner=processor, first_step_shared=share_prefill)
     # whole-logits steps hand over at most n_keep candidates per row (all a group can keep); the sliced
     # step emits every allowed token
-    keep = 0 if lm_head_slice else processor.keep_top_for(state.n_keep)
+    keep = 0 if (lm_head_slice or lm_head) else processor.keep_top_for(state.n_keep)
     cmax = processor.candidate_width(state.n_keep if keep else 0)
     cand = Candidates(B * K, cmax, dev)
 
@@ -184,9 +226,10 @@ def constrained_generate(
 
     last_only = {"logits_to_keep": 1} if "logits_to_keep" in inspect.signature(model.forward).parameters else {}
     sliced = None
-    if lm_head_slice:
-        sliced = SlicedLMHead(model.get_output_embeddings(), lm_head_slice, lm_head_overlap)
-        body = model.base_model  # the transformer without the LM head
+    if lm_head_slice or lm_head:
+        sliced = (FusedLMHead(model.get_output_embeddings()) if lm_head else
+                  SlicedLMHead(model.get_output_embeddings(), lm_head_slice, lm_head_overlap))
+        body = _model_body(model)  # the transformer without the LM head
 
         def forward(**kw):
             out = body(**kw)
@@ -237,8 +280,13 @@ def constrained_generate(
             break
         if step >= max_new_tokens:
             break
-        # ---- model side of the next step: re-order the cache, feed the tokens just chosen
-        reorder_generated_suffix(cache, res.next_parent.long(), T)
+        # ---- model side of the next step: re-order the cache, feed the tokens just chosen.  Rows of a group
+        # share their prompt's cache bit for bit only when one prefill was copied K times; K separately
+        # prefilled copies are re-ordered whole, as generate() does
+        if share_prefill:
+            reorder_generated_suffix(cache, res.next_parent.long(), T)
+        else:
+            cache.reorder_cache(res.next_parent.long())
         new_tokens = state.running_sequences.view(B * K, -1)[:, state.cur_len - 1 : state.cur_len]
         mask = torch.cat([mask, torch.ones((B * K, 1), dtype=mask.dtype, device=dev)], dim=1)
         logits, cache = forward(input_ids=new_tokens, attention_mask=mask, position_ids=next_pos,
@@ -251,7 +299,8 @@ def constrained_generate(
 
 def make_fused_generate(model, processor, num_beams: int = 50, max_completion_length: int = 128,
                         length_penalty: float = 1.0, max_steps: Optional[int] = None,
-                        lm_head_slice: Optional[int] = None, lm_head_overlap: bool = False):
+                        lm_head_slice: Optional[int] = None, lm_head_overlap: bool = False,
+                        lm_head: Optional[str] = None):
     """A ``generate(*args, **kwargs)`` to install on a model in place of the wrapper the reference
     builds in ``_make_mimigenrec_generate`` (MIMIGenRec.py:9-81): the trainer hands over every prompt
     ``num_beams`` times ([B * K, T] ``input_ids`` / ``attention_mask``), the wrapper keeps the first copy
@@ -274,7 +323,7 @@ def make_fused_generate(model, processor, num_beams: int = 50, max_completion_le
         out = constrained_generate(model, prompts.contiguous(), processor, K, max_completion_length,
                                    attention_mask=None if mask is None else mask.contiguous(),
                                    length_penalty=length_penalty, num_return_sequences=K, max_steps=max_steps,
-                                   lm_head_slice=lm_head_slice, lm_head_overlap=lm_head_overlap)
+                                   lm_head_slice=lm_head_slice, lm_head_overlap=lm_head_overlap, lm_head=lm_head)
         return out.sequences
 
     return generate

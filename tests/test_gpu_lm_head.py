@@ -107,3 +107,61 @@ def test_fused_lm_head_reports_row_errors_and_refuses_what_it_does_not_serve():
     with pytest.raises(_lib.GenrecHipError, match="multiple of 64"):
         proc.lm_head_candidates_into(torch.tensor([[5, 11, 12, 13]] * 2, device=dev), hidden[:, :32].contiguous(),
                                      weight[:, :32].contiguous(), cand)
+
+
+@pytest.mark.parametrize("kind,share", [("count", True), ("fixed", True), ("count", False)])
+def test_generation_with_the_fused_lm_head_equals_generation_from_whole_logits(kind, share):
+    """constrained_generate(lm_head="fused") -- transformer body, LM head multiplied inside the processor call --
+    returns the beams of the same loop fed the model's own bf16 logits.  The fused head keeps fp32 sums where the
+    model rounds its logits to bf16, so scores agree to bf16 resolution and beams are compared where the whole-logits
+    run leaves a clear margin between neighbours."""
+    from transformers import Qwen2Config, Qwen2ForCausalLM
+
+    from genrec_amd.generate import constrained_generate
+    from helpers import load_npz
+
+    dev = _dev()
+    data, meta = load_npz("beams.npz")
+    prefix, eos, pad, V = meta["prefix"], meta["eos"], meta["pad"], meta["V"]
+    fn = create_prefix_allowed_tokens_fn(FlatTrie(data["trie_sequences"].tolist()), prefix)
+    K = 8
+    torch.manual_seed(11)
+    cfg = Qwen2Config(vocab_size=V, hidden_size=64, intermediate_size=128, num_hidden_layers=2,
+                      num_attention_heads=2, num_key_value_heads=2, max_position_embeddings=128,
+                      eos_token_id=eos, pad_token_id=pad, bos_token_id=None, tie_word_embeddings=False)
+    model = Qwen2ForCausalLM(cfg).eval()
+    with torch.no_grad():
+        for p in model.parameters():
+            p.mul_(4.0)
+    model = model.to(dev).to(torch.bfloat16)
+    cls = ConstrainedLogitsProcessor if kind == "count" else FixedHintConstrainedLogitsProcessor
+    g = torch.Generator().manual_seed(21)
+    rows, lens = [], [9, 6, 11, 8]
+    for n in lens:
+        body = torch.randint(20, 90, (n,), generator=g).tolist()
+        rows.append([pad] * (max(lens) - n) + body + prefix)
+    prompts = torch.tensor(rows, device=dev)
+    mask = (prompts != pad).long()
+    # reference run: the same body, the head applied in fp32 to the bf16 hidden states (what the fused head computes)
+    head = model.get_output_embeddings()
+
+    class _Fp32Head(torch.nn.Module):
+        def __init__(self, w):
+            super().__init__()
+            self.weight = w
+
+        def forward(self, h):
+            return h.float() @ self.weight.float().T
+
+    model.set_output_embeddings(_Fp32Head(head.weight))
+    want = constrained_generate(model, prompts, cls(fn, K, 3, prefix, eos), K, 8, attention_mask=mask,
+                                eos_token_id=eos, pad_token_id=pad, length_penalty=0.0, share_prefill=share)
+    model.set_output_embeddings(head)
+    got = constrained_generate(model, prompts, cls(fn, K, 3, prefix, eos), K, 8, attention_mask=mask,
+                               eos_token_id=eos, pad_token_id=pad, length_penalty=0.0, share_prefill=share,
+                               lm_head="fused")
+    live = want.sequences_scores > -1e8
+    assert int(live.sum()) >= 12 and got.steps == want.steps
+    assert torch.equal(got.sequences[live], want.sequences[live])
+    assert torch.equal(got.beam_indices[live], want.beam_indices[live])
+    assert float((got.sequences_scores[live] - want.sequences_scores[live]).abs().max()) <= 1e-4
