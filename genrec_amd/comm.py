@@ -28,7 +28,13 @@ def unique_id() -> bytes:
 
 
 class RcclComm:
-    """One rank's end of an RCCL communicator bound to ``device``.  Creating it is collective."""
+    """One rank's end of an RCCL communicator bound to ``device``.  Creating it is collective.
+
+    The all-gather runs on the caller's current stream through this communicator, beside whatever
+    ``torch.distributed`` does with its own NCCL communicator on its own stream: collectives of the two must
+    not be in flight on a rank at the same time -- every rank has to issue them in one common order, so
+    synchronise the stream (or wait for the torch collective's work handle) before switching from one to
+    the other.  ``close()`` waits for the device before the communicator is destroyed."""
 
     def __init__(self, n_ranks: int, rank: int, comm_id: bytes, device):
         if len(comm_id) != ID_BYTES:

@@ -110,6 +110,8 @@ extern "C" int grx_comm_create(const void* id, int32_t n_ranks, int32_t rank, gr
 
 extern "C" int grx_comm_destroy(grx_comm* c) {
     if (!c) return GRX_OK;
+    // gathers of this communicator may still be queued on the caller's streams: let them finish first
+    (void)hipDeviceSynchronize();
     if (c->comm && g_rccl.comm_destroy) (void)g_rccl.comm_destroy(c->comm);
     delete c;
     return GRX_OK;

@@ -33,7 +33,7 @@ int grx_check_step_args(const char* who, const grx_trie* trie, const grx_state* 
 // (max, sum) pairs the last one to arrive merges through device-scope atomics.
 // The caller's workspace holds the arrival counters ([GRX_SPLIT_MAX_ROWS] int32, zero
 // between calls) followed by the partial (max, sum) pairs; the row plans come after them.
-#define GRX_SPLIT_MAX_ROWS 1024
+#define GRX_SPLIT_MAX_ROWS 512
 #define GRX_SPLIT_MAX_PARTS 2048
 #define GRX_SPLIT_COUNT_BYTES (GRX_SPLIT_MAX_ROWS * 4)
 #define GRX_WS_PLAN_OFFSET (GRX_SPLIT_COUNT_BYTES + GRX_SPLIT_MAX_PARTS * 8)

@@ -5,6 +5,9 @@
 #include <math.h>
 #include <string.h>
 
+#include <atomic>
+#include <mutex>
+
 #include "common.h"
 
 #define SC_THREADS 256
@@ -316,6 +319,32 @@ __global__ __launch_bounds__(SC_THREADS) void group_advantage_kernel(const float
     if (gstd) gstd[r] = sd;
 }
 
+// Scratch words for scale "batch": 64 slots of 16 bytes per GPU, handed out round robin, so that calls
+// in flight on different streams of one GPU do not share a word (the 65th call reuses the first slot).
+#define BATCH_STAT_SLOTS 64
+#define BATCH_STAT_DEVICES 64
+static __device__ __align__(16) float g_batch_stats[BATCH_STAT_SLOTS * 4];
+static float* g_batch_stats_ptr[BATCH_STAT_DEVICES];
+static std::atomic<unsigned> g_batch_stats_next{0};
+static std::mutex g_batch_stats_mutex;
+
+static int batch_stats_slot(const char* who, float** out) {
+    int dev = -1;
+    GRX_CHECK_HIP(hipGetDevice(&dev));
+    GRX_REQUIRE(dev >= 0 && dev < BATCH_STAT_DEVICES, GRX_E_UNSUPPORTED, "%s: device index %d not supported", who, dev);
+    {
+        std::lock_guard<std::mutex> guard(g_batch_stats_mutex);
+        if (g_batch_stats_ptr[dev] == nullptr) {
+            void* p = nullptr;  // the array's address on THIS device (its name is only a handle in host code)
+            GRX_CHECK_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(g_batch_stats)));
+            GRX_REQUIRE(p != nullptr, GRX_E_HIP, "%s: no device address for the batch statistics", who);
+            g_batch_stats_ptr[dev] = reinterpret_cast<float*>(p);
+        }
+    }
+    *out = g_batch_stats_ptr[dev] + 4 * (g_batch_stats_next.fetch_add(1) % BATCH_STAT_SLOTS);
+    return GRX_OK;
+}
+
 extern "C" int grx_group_advantage(const float* rewards_per_func, const float* weights, int32_t R, int32_t n_funcs,
                                    int32_t K, int32_t scale, float eps, float* rewards, float* advantages,
                                    float* group_mean, float* group_std, void* stream_) {
@@ -329,18 +358,19 @@ extern "C" int grx_group_advantage(const float* rewards_per_func, const float* w
     GRX_REQUIRE(rewards_per_func && weights, GRX_E_INVALID, "%s: null input", who);
     float* stats = nullptr;
     if (scale == 2) {
-        // one word of stream-ordered scratch for the batch std (freed in stream order below)
-        GRX_CHECK_HIP(hipMallocAsync((void**)&stats, 16, stream));
+        // the batch std travels from the reducing kernel to the normalising one through a word of a device
+        // array that is part of the library image (nothing is allocated: the call can be captured in a graph)
+        const int rc = batch_stats_slot(who, &stats);
+        if (rc != GRX_OK) return rc;
         hipLaunchKernelGGL(batch_std_kernel, dim3(1), dim3(BS_STAT_THREADS), 0, stream, rewards_per_func, weights, R,
                            n_funcs, stats);
+        GRX_CHECK_HIP(hipGetLastError());
     }
     const int rows_per_block = (SC_THREADS / K) * K;
     hipLaunchKernelGGL(group_advantage_kernel, dim3((R + rows_per_block - 1) / rows_per_block), dim3(SC_THREADS), 0,
                        stream, rewards_per_func, weights, R, n_funcs, K, rows_per_block, scale, eps, stats, rewards,
                        advantages, group_mean, group_std);
-    const hipError_t launched = hipGetLastError();
-    if (stats) (void)hipFreeAsync(stats, stream);
-    GRX_CHECK_HIP(launched);
+    GRX_CHECK_HIP(hipGetLastError());
     return GRX_OK;
 }
 
@@ -407,6 +437,14 @@ struct TokenPrefixArgs {
     int rows_per_block;
 };
 
+// A row's ground-truth length as the kernel uses it: never beyond the row's own gt_stride entries (a
+// length that disagrees with the buffer must not turn into reads behind the row), never negative.
+__device__ __forceinline__ int bounded_gt_len(const grx_token_prefix_args& u, int r) {
+    int n = u.gt_len[r];
+    if (u.gt_stride > 0 && (int64_t)n > u.gt_stride) n = (int)u.gt_stride;
+    return n > 0 ? n : 0;
+}
+
 __global__ __launch_bounds__(SC_THREADS) void token_prefix_kernel(TokenPrefixArgs a) {
     __shared__ float s_seq[SC_THREADS];
     __shared__ float s_ndcg[SC_THREADS];
@@ -422,7 +460,7 @@ __global__ __launch_bounds__(SC_THREADS) void token_prefix_kernel(TokenPrefixArg
         const int64_t* __restrict__ ids = u.completion_ids + (int64_t)r * u.ids_stride;
         const float* __restrict__ mask = u.completion_mask + (int64_t)r * Tc;
         const int64_t* __restrict__ gt = u.gt_ids + (int64_t)r * u.gt_stride;
-        const int gt_len = u.gt_len[r];
+        const int gt_len = bounded_gt_len(u, r);
         int nv = 0;
         int64_t last = -1;
         for (int p = 0; p < Tc; ++p)
@@ -463,7 +501,7 @@ __global__ __launch_bounds__(SC_THREADS) void token_prefix_kernel(TokenPrefixArg
     const float* __restrict__ mask = u.completion_mask + (int64_t)r * Tc;
     const int64_t* __restrict__ ids = u.completion_ids + (int64_t)r * u.ids_stride;
     const int64_t* __restrict__ gt = u.gt_ids + (int64_t)r * u.gt_stride;
-    const int gt_len = u.gt_len[r];
+    const int gt_len = bounded_gt_len(u, r);
     const float per_tok_f = (float)per_tok;
     // the row's token rewards / error mask again, position by position (cheaper than keeping them)
     auto for_each_position = [&](auto&& body) {
@@ -532,7 +570,11 @@ extern "C" int grx_token_prefix_advantages(const grx_token_prefix_args* args, vo
     GRX_REQUIRE(u.R >= 0 && u.Tc >= 0 && u.K >= 1, GRX_E_INVALID, "%s: bad shape", who);
     GRX_REQUIRE(u.K <= SC_THREADS, GRX_E_UNSUPPORTED, "%s: at most %d rows per group", who, SC_THREADS);
     GRX_REQUIRE(u.R % u.K == 0, GRX_E_INVALID, "%s: %d rows do not split into groups of %d", who, u.R, u.K);
-    if (u.R == 0 || u.Tc == 0) return GRX_OK;
+    if (u.R == 0) return GRX_OK;
+    if (u.Tc == 0) {  // no completion tokens: the reference's sequence rewards are zeros, the [R, 0] outputs are empty
+        if (u.seq_rewards) GRX_CHECK_HIP(hipMemsetAsync(u.seq_rewards, 0, sizeof(float) * (size_t)u.R, (hipStream_t)stream));
+        return GRX_OK;
+    }
     GRX_REQUIRE(u.completion_ids && u.completion_mask && u.gt_ids && u.gt_len && u.token_advantages, GRX_E_INVALID,
                 "%s: null pointer", who);
     GRX_REQUIRE(u.ids_stride >= u.Tc && u.gt_stride >= 0, GRX_E_INVALID, "%s: bad strides", who);

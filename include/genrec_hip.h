@@ -282,6 +282,10 @@ GRX_API int grx_constrained_candidates_noalloc(const grx_trie* trie, grx_state* 
  * reported -- must be ordered before the others and grx_constrained_finish after
  * all of them (one stream, or events).  partials is device fp32 [R, n_slots, 2].
  * Not available with assume_normalized or keep_top (both need whole rows).
+ * The library cannot tell whether every slice was fed: grx_constrained_finish merges all
+ * n_slots pairs and reads candidate entries 1 .. count whatever wrote them, so slices that do not
+ * cover [0, v_total) exactly once, or a slot left unfilled, yield log-probabilities built from
+ * stale memory without any error (the Python ChunkedStep checks coverage and the fed count).
  *
  * With the fused repetition penalty (grx_constraint.repetition_penalty) every partial
  * call also copies the raw logits of the row's own tokens ids[r, penalty_skip:T) that
@@ -590,8 +594,10 @@ GRX_API int grx_hit_ranks(const int32_t* beams, const int32_t* target, int32_t n
  * [R, n_funcs] (after the all-gather), weights device fp32 [n_funcs].
  * Outputs (device fp32 [R], any may be NULL): rewards, advantages,
  * group_mean, group_std.  Scale 2 first reduces all R rows once (one extra
- * single-workgroup kernel) into a word of stream-ordered scratch
- * (hipMallocAsync / hipFreeAsync on `stream`); scales 0 and 1 allocate nothing.
+ * single-workgroup kernel) into a scratch word inside the library image (64
+ * words per GPU, handed out round robin: up to 64 such calls may be in flight
+ * on one GPU).  No scale allocates anything, so the call can be captured in a
+ * HIP graph.
  */
 GRX_API int grx_group_advantage(const float* rewards_per_func, const float* weights, int32_t R, int32_t n_funcs,
                         int32_t K, int32_t scale, float eps, float* rewards, float* advantages,
@@ -602,7 +608,12 @@ GRX_API int grx_group_advantage(const float* rewards_per_func, const float* weig
  * matrices that the reference issues through accelerate (`gather(rewards_per_func)`,
  * fixed_hint_grpo_trainer.py:382; token_prefix_grpo_trainer.py:215,241-242,249,274), as an RCCL
  * all-gather enqueued on the caller's stream -- reward kernel, gather and advantage kernel are then
- * ordered by that one stream.  One process per GPU: rank 0 draws an id with grx_comm_unique_id
+ * ordered by that one stream.  The communicator is the library's own: if the process also drives
+ * torch.distributed's NCCL communicator over the same ranks (on its own stream), collectives of the
+ * two must not be in flight at the same time on a rank -- every rank has to issue them in one common
+ * order (synchronise the stream before switching communicators).  grx_comm_destroy synchronises the
+ * device first, so no gather of this communicator is cut short.
+ * One process per GPU: rank 0 draws an id with grx_comm_unique_id
  * (GRX_COMM_ID_BYTES opaque bytes), hands it to the other ranks by any means (a file, a
  * torch.distributed store), and every rank calls grx_comm_create with the device it will use
  * current (collective: returns when all n_ranks have called).  grx_comm_allgather places rank i's
@@ -654,7 +665,8 @@ GRX_API int grx_group_normalize_tokenwise(const float* values, const float* mask
  * The reference gathers the rewards of all ranks first and slices its own rows out again;
  * groups never straddle ranks, so the local rows give the same values.  All pointers are
  * device memory; completion_mask / outputs are fp32 [R, Tc] contiguous, seq_rewards [R];
- * token_rewards, seq_rewards, error_mask may be null.
+ * token_rewards, seq_rewards, error_mask may be null.  gt_len[i] must not exceed the gt_stride
+ * entries row i owns (larger values are cut to it); with Tc == 0 only seq_rewards is written (zeros).
  */
 typedef struct grx_token_prefix_args {
     const int64_t* completion_ids;
