@@ -52,6 +52,7 @@ static int host_checks(void) {
     printf("sizeof_grx_beam_init_args=%zu\n", sizeof(grx_beam_init_args));
     printf("sizeof_grx_cand=%zu\n", sizeof(grx_cand));
     printf("sizeof_grx_chunk=%zu\n", sizeof(grx_chunk));
+    printf("sizeof_grx_lm_head=%zu\n", sizeof(grx_lm_head));
     printf("noalloc_max_rows=%d\n", (int)grx_noalloc_max_rows());
     CHECK(grx_noalloc_max_rows() == GRX_NOALLOC_MAX_ROWS, "library and header disagree on the scratch size");
     CHECK(grx_chunk_parts(8192, 8192, GRX_BF16) == 1 && grx_chunk_parts(16, 65536, GRX_BF16) > 1,
@@ -352,6 +353,55 @@ static int gpu_checks(void) {
         }
     }
     printf("beam_step_groups_checked=%d\n", NB);
+
+    /* the same step as ONE call (grx_constrained_beam_step), the processor call planned ahead by the beam
+     * initialisation so that the streaming kernel itself carries the groups' beam steps: same candidate
+     * rows, same top candidates, bit for bit */
+    {
+        grx_plan_request req;
+        void *d_score2, *d_parent2, *d_token2;
+        float h_score2[NB * 2 * NK];
+        int32_t h_token2[NB * 2 * NK], h_parent2[NB * 2 * NK];
+        grx_cand* h_again = (grx_cand*)malloc(sizeof(grx_cand) * NR * (size_t)stride);
+        CHECK(hipMalloc(&d_score2, sizeof(h_score2)) == 0 && hipMalloc(&d_parent2, sizeof(h_parent2)) == 0 &&
+                  hipMalloc(&d_token2, sizeof(h_token2)) == 0,
+              "hipMalloc");
+        memset(&req, 0, sizeof(req));
+        req.trie = trie; req.state = state; req.con = &con; req.workspace = d_ws; req.workspace_bytes = ws_bytes;
+        CHECK(grx_state_set_count(state, 0, NULL) == GRX_OK, "grx_state_set_count");
+        init.plan_next = &req;
+        CHECK(grx_beam_init(&init, NULL) == GRX_OK, "grx_beam_init with a plan request");
+        init.plan_next = NULL;
+        CHECK(hipMemset(d_cand, 0xEE, sizeof(grx_cand) * NR * (size_t)stride) == 0, "scribble");
+        rows.planned = 1;
+        step.topk_score = (float*)d_score2; step.topk_parent = (int32_t*)d_parent2; step.topk_token = (int32_t*)d_token2;
+        CHECK(grx_constrained_beam_step(trie, state, &rows, &con, (grx_cand*)d_cand, stride, NCMAX, d_ws, ws_bytes, &step,
+                                        NULL) == GRX_OK,
+              "grx_constrained_beam_step");
+        rows.planned = 0;
+        CHECK(grx_state_read(state, st, NULL) == GRX_OK && st[0] == 1 && st[1] == GRX_ROWERR_NONE,
+              "the one-call step counts as one processor call");
+        CHECK(hipMemcpy(h_score2, d_score2, sizeof(h_score2), 2) == 0 && hipMemcpy(h_token2, d_token2, sizeof(h_token2), 2) == 0 &&
+                  hipMemcpy(h_parent2, d_parent2, sizeof(h_parent2), 2) == 0 &&
+                  hipMemcpy(h_again, d_cand, sizeof(grx_cand) * NR * (size_t)stride, 2) == 0,
+              "download");
+        for (r = 0; r < NR; ++r)
+            CHECK(memcmp(h_again + (size_t)r * stride, h_cand + (size_t)r * stride, sizeof(grx_cand) * 16) == 0,
+                  "one-call step: the candidate rows of the processor call");
+        for (b = 0; b < NB; ++b)
+            for (i = 0; i < 4; ++i)  /* the live slots (the rest are -1e9 placeholders) */
+                CHECK(h_score2[b * 2 * NK + i] == h_score[b * 2 * NK + i] && h_token2[b * 2 * NK + i] == h_token[b * 2 * NK + i] &&
+                          h_parent2[b * 2 * NK + i] == h_parent[b * 2 * NK + i],
+                      "one-call step: the top candidates of the beam step");
+        step.cmax = NCMAX + 1;
+        CHECK(grx_constrained_beam_step(trie, state, &rows, &con, (grx_cand*)d_cand, stride, NCMAX, d_ws, ws_bytes, &step,
+                                        NULL) == GRX_E_INVALID,
+              "a beam step that does not read this call's candidate buffer is refused");
+        step.cmax = NCMAX;
+        printf("one_call_step_checked=1\n");
+        hipFree(d_score2); hipFree(d_parent2); hipFree(d_token2);
+        free(h_again);
+    }
 
     for (h = 0; h < 2; ++h)
         for (i = 0; i < 7; ++i) hipFree(buf[h][i]);

@@ -46,6 +46,7 @@ def test_header_is_c99_and_the_python_mirror_has_the_same_layout(tmp_path):
     assert int(facts["sizeof_grx_beam_step_args"]) == C.sizeof(_lib.GrxBeamStepArgs)
     assert int(facts["sizeof_grx_beam_init_args"]) == C.sizeof(_lib.GrxBeamInitArgs)
     assert int(facts["sizeof_grx_chunk"]) == C.sizeof(_lib.GrxChunk)
+    assert int(facts["sizeof_grx_lm_head"]) == C.sizeof(_lib.GrxLmHead)
     assert int(facts["noalloc_max_rows"]) == 65536
     assert int(facts["candidate_stride_242"]) == 256
     assert "null trie" in facts["null_trie_message"]
@@ -65,6 +66,7 @@ def test_plain_c_client_decodes_one_step_on_the_gpu(tmp_path):
     facts = _facts(run.stdout)
     assert float(facts["max_abs_logp_error"]) <= 1e-5  # fp32 tolerance of the log-probs
     assert int(facts["beam_step_groups_checked"]) == 3
+    assert int(facts["one_call_step_checked"]) == 1  # grx_constrained_beam_step == the two calls, bit for bit
     assert int(facts["noalloc_rows_identical"]) == 12
     assert float(facts["sliced_max_abs_logp_difference"]) <= 1e-5
     # dense form kept from call to call == a fresh dense result, on both calls (4 tokens, then 1 per row)
