@@ -357,7 +357,7 @@ def baseline_metric() -> str:
 
 
 KERNEL_SOURCES = ("genrec_amd/csrc/masked_logsoftmax.hip", "genrec_amd/csrc/lse_math.h", "genrec_amd/csrc/common.h",
-                  "genrec_amd/csrc/resolve.h", "include/genrec_hip.h")
+                  "genrec_amd/csrc/resolve.h", "genrec_amd/csrc/beam_body.h", "include/genrec_hip.h")
 
 
 def kernel_sources_sha256() -> str:
@@ -372,19 +372,35 @@ def kernel_sources_sha256() -> str:
     return h.hexdigest()
 
 
+def workload_key(args) -> str:
+    """What identifies a workload for the recorded counter figures: everything that changes which kernel
+    runs or how many bytes it moves."""
+    return (f"{args.trie}|{args.processor}|batch={args.batch}|beams={args.beams}|{args.dtype}|"
+            f"prompt={args.prompt_len}|penalty={args.repetition_penalty}")
+
+
 def recorded_traffic(args, alg_bytes):
     """HBM bytes per launch of the dominant kernel from hardware counters.
 
     Counters cannot be read from inside this process: they come from separate
     `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` passes over this same
-    command, whose per-launch averages are kept in profiles/*_pmc_summary.json
+    command, whose per-launch averages are kept under profiles/ -- the headline
+    workload's in r*_pmc_summary.json, the other configurations' in r*_<config>_pmc.json
     (FETCH_SIZE is in KiB and, on gfx950, counts half the bytes of a wide
-    coalesced stream, hence the factor 2 applied there).  The recorded figure
+    coalesced stream, hence the factor 2 applied there).  A recorded figure
     only applies to the workload and to the kernel sources (their SHA-256 is kept
-    in the summary) it was collected on; anything else reports null.
+    with it) it was collected on; anything else reports null.
     """
     import glob
 
+    sha = kernel_sources_sha256()
+    key = workload_key(args)
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")), reverse=True):
+        with open(path) as f:
+            rec = json.load(f)
+        if rec.get("workload_key") == key and rec.get("kernel_sources_sha256") == sha and \
+                int(rec.get("algorithmic_bytes_per_launch", -1)) == int(alg_bytes):
+            return float(rec["hbm_bytes_per_launch"]["total"]), os.path.relpath(path, ROOT)
     if args.processor != "count" or args.dtype != "bf16" or args.trie != "Instruments":
         return None, None
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
@@ -394,10 +410,9 @@ def recorded_traffic(args, alg_bytes):
         summary = json.load(f)
     rec = summary["masked_lsm_kernel_hbm_bytes_per_launch"]
     # counters taken on other kernel sources (or on another workload) say nothing about this build
-    if summary.get("kernel_sources_sha256") != kernel_sources_sha256() or int(rec["algorithmic"]) != int(alg_bytes):
+    if summary.get("kernel_sources_sha256") != sha or int(rec["algorithmic"]) != int(alg_bytes):
         return None, None
     return float(rec["total"]), os.path.relpath(files[-1], ROOT)
-
 
 
 def launch_ranks(n: int) -> int:

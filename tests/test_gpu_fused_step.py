@@ -24,10 +24,10 @@ from test_gpu_processors import _dev
 pytestmark = pytest.mark.gpu
 
 
-def _setup(trie_name, K, cls, with_prefix_ids=True):
+def _setup(trie_name, K, cls, with_prefix_ids=True, synth=(600, 3, 24, 3)):
     tmp = tempfile.mkdtemp()
     if trie_name.startswith("synth"):
-        path = write_index(f"{tmp}/s.index.json", synthetic_index(600, 3, 24, seed=3))
+        path = write_index(f"{tmp}/s.index.json", synthetic_index(synth[0], synth[1], synth[2], seed=synth[3]))
     else:
         path = write_index_file(trie_name, tmp)
     tok = SidTokenizer.from_index(path)
@@ -180,3 +180,45 @@ def test_fused_step_refuses_a_beam_step_on_other_candidates():
     with pytest.raises(_lib.GenrecHipError, match="candidate buffer"):
         proc.candidates_into(state.flat_running_sequences(), x, cand, beam_step=a)
     assert proc.count == 0  # a refused call does not count
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_fused_step_on_random_searches(seed):
+    """Random beam counts (1 .. 16), group counts, trie shapes, dtypes, both processors, with and without
+    prefix_ids, plans made ahead or not, rows cut or whole: the one call against the two calls."""
+    rng = np.random.default_rng(1000 + seed)
+    dev = _dev()
+    K = int(rng.integers(1, 17))
+    B = int(rng.integers(1, 40))
+    levels_n = int(rng.integers(2, 5))
+    cb = int(rng.choice([4, 12, 40, 90]))
+    cls = ConstrainedLogitsProcessor if rng.random() < 0.6 else FixedHintConstrainedLogitsProcessor
+    with_prefix = bool(rng.random() < 0.6) or cls is FixedHintConstrainedLogitsProcessor
+    tok, trie, make, levels = _setup("synth", K, cls, with_prefix_ids=with_prefix,
+                                     synth=(int(rng.integers(30, 900)), levels_n, cb, seed))
+    dtype = [torch.float32, torch.bfloat16, torch.float16][int(rng.integers(0, 3))]
+    prompts = torch.from_numpy(sample_decode_rows(trie, B, 1, 0, prompt_len=int(rng.integers(1, 40)), seed=seed)).to(dev)
+    g = torch.Generator(device=dev).manual_seed(seed)
+    logits = [(torch.randn((B * K, tok.vocab_size_padded), generator=g, device=dev) * 3).to(dtype) for _ in range(levels)]
+    plan, keep = bool(rng.random() < 0.7), bool(rng.random() < 0.7)
+    want = _run(make, tok, prompts, K, levels, logits, fused=False, generations=2, keep=keep, plan=plan)
+    got = _run(make, tok, prompts, K, levels, logits, fused=True, generations=2, keep=keep, plan=plan)
+    _assert_same(got, want)
+
+
+def test_one_launch_route_with_thousands_of_rows():
+    """The library only fuses launches of up to 512 rows by itself (larger ones are faster as two kernels);
+    GRX_FUSE_MAX_ROWS lifts the limit.  In a process of its own (the limit is read once), the headline shape
+    and a 640-row shape through the one-launch route, against the two calls."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import torch; import test_gpu_fused_step as t; "
+            "t.test_fused_step_at_the_headline_shape(); "
+            "t.test_fused_step_equals_the_two_calls(t.ConstrainedLogitsProcessor, 40, torch.bfloat16); print('OK')"
+            % (root, os.path.join(root, "tests")))
+    env = dict(os.environ, GRX_FUSE_MAX_ROWS="1000000")
+    run = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0 and "OK" in run.stdout, run.stdout[-2000:] + run.stderr[-2000:]

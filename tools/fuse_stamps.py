@@ -53,6 +53,8 @@ for gen in range(2):
         assert h.grx_debug_read_fuse_stamps(buf.ctypes.data) == 0
         st = buf.reshape(1024, 16).astype(np.int64)[: min(B, 1024)]
         t0 = st[:, 0].min()
+        print(f"depth {d}: first workgroup of the launch -> first beam step {(t0 - st[0, 15]) / 100:.1f} us, -> last beam step done "
+              f"{(st[:, 14].max() - st[0, 15]) / 100:.1f} us")
         print(f"depth {d}: beam steps start {((st[:, 0] - t0) / 100).min():.1f} .. {((st[:, 0] - t0) / 100).max():.1f} us after the "
               f"first one; whole step median {np.median(st[:, 14] - st[:, 0]) / 100:.1f} us, p90 "
               f"{np.percentile(st[:, 14] - st[:, 0], 90) / 100:.1f}, max {(st[:, 14] - st[:, 0]).max() / 100:.1f}")

@@ -47,8 +47,25 @@ def main():
     sys.path.insert(0, ROOT)
     import bench
 
+    key = None
+    try:  # the key bench.py looks a recorded figure up by
+        import argparse
+
+        ap = argparse.ArgumentParser()
+        ap.add_argument("--trie", default="Instruments")
+        ap.add_argument("--processor", default="count")
+        ap.add_argument("--batch", type=int, default=512)
+        ap.add_argument("--beams", type=int, default=16)
+        ap.add_argument("--dtype", default="bf16")
+        ap.add_argument("--prompt-len", type=int, default=61)
+        ap.add_argument("--repetition-penalty", type=float, default=1.0)
+        known, _ = ap.parse_known_args(bench_args)
+        key = bench.workload_key(known)
+    except SystemExit:
+        pass
     out = {
         "bench_args": bench_args,
+        "workload_key": key,
         "workload": line["config"]["workload"],
         "value_steps_per_s": line["value"],
         "ms_per_step": line["ms_per_step"],
