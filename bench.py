@@ -661,8 +661,10 @@ def main() -> None:
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": ("masked_lsm_kernel (compact output)" if (args.no_fused_step or args.beams > 16
-                                                                        or args.repetition_penalty != 1.0)
+                # launches of up to 512 rows carry their groups' beam steps (the library's own choice)
+                "kernel": ("masked_lsm_kernel (compact output)"
+                           if (args.no_fused_step or args.beams > 16 or args.repetition_penalty != 1.0
+                               or R > int(os.environ.get("GRX_FUSE_MAX_ROWS", "512")))
                            else "masked_lsm_beam_kernel (compact candidates; a prompt group's beam step runs in the "
                                 "workgroup that emits the group's last row)"),
                 "achieved": achieved,
