@@ -17,12 +17,19 @@
 #define BS_PREFETCH 16         // beams whose candidate rows are fetched in the opening batch of loads
 #define BS_TAIL_K 64           // beams / positions per row of the sequence tails staged in LDS
 #define BS_TAIL_W 16
+#define BS_COLS 256            // candidate columns a row is dealt over (one per thread of a 256-thread part)
+#define BS_MID_THREADS 1024    // the instantiation for groups of up to 64 beams with rows of at most BS_COLS candidates:
+#define BS_MID_K 64            // ... four 256-thread parts, each holding one entry of every fourth beam in registers
+#define BS_MID_KEEP 128
+#define BS_MID_HOLD 16
 
 struct BeamDerived {
     float fin_div;    // (cur_len + 1 - prompt_len) ** length_penalty
     float heur_div;   // best_hypothetical_length ** length_penalty
     int reg_keys;     // every candidate slot is covered by the opening batch of loads: keys stay in registers
     int tails_in_lds; // the re-ordered parts of the sequence / parent rows fit the LDS tail buffers
+    int hold_keys;    // HOLD instantiation: part q = tid / BS_COLS of the workgroup keeps entry (tid - 37 k) mod BS_COLS of the
+                      // beams k = q, q + parts, ... in registers, fetched in the opening batch of loads
 };
 
 // 64-bit sort key: ordered score in the high word; the low word is the
@@ -62,19 +69,26 @@ __device__ __forceinline__ grx_cand cand_load(const grx_cand* p) {
 // survivors of the threshold cut, tail buffers for TAIL_K beams.  The common search (at most 16
 // beams, 64 kept candidates) gets by with 14 KB where the largest supported one takes 54 KB, and the
 // number of groups a CU works on at once follows from that.
-// b: the group.  Every thread of a 256-thread workgroup must call it.
-template <int MAXK, int MAXKEEP, int SURV_CAP, int TAIL_K, bool COH>
+// NT: threads of the workgroup (a multiple of BS_COLS).  HOLD > 0: entries per thread the instantiation can keep in
+// registers (d.hold_keys; K <= HOLD * NT / BS_COLS).
+// b: the group.  Every thread of the workgroup must call it.
+template <int MAXK, int MAXKEEP, int SURV_CAP, int TAIL_K, bool COH, int HOLD = 0, int NT = BS_THREADS>
 __device__ __forceinline__ void beam_step_group(const grx_beam_step_args& a, const BeamDerived& d, const PlanCtx& pc,
                                                 grx_row_plan* __restrict__ plan_out, const int b) {
+    constexpr int NW = NT / GRX_WAVE;
+    constexpr int PARTS = NT / BS_COLS;
+    static_assert(NT % BS_COLS == 0 && (NT & (NT - 1)) == 0, "workgroup = whole 256-thread parts");
     __shared__ int s_cnt[MAXK];
     __shared__ int s_base[MAXK + 1];
     __shared__ float s_runin[MAXK];
     __shared__ unsigned char s_fdone_in[MAXK];
-    __shared__ unsigned long long s_tmax[BS_THREADS];
+    __shared__ unsigned long long s_tmax[NT];
+    __shared__ unsigned long long s_pmax[HOLD > 0 ? BS_COLS : 1];  // HOLD: column maxima over the parts
+    __shared__ int s_prank[HOLD > 0 ? BS_COLS : 1];                // ... and their ranks
     __shared__ unsigned long long s_surv[SURV_CAP];
     __shared__ int s_nsurv;
     __shared__ unsigned long long s_thresh;
-    __shared__ unsigned long long s_red[2][BS_WAVES];
+    __shared__ unsigned long long s_red[2][NW];
     __shared__ float s_score[MAXKEEP];
     __shared__ int s_parent[MAXKEEP];
     __shared__ int s_tok[MAXKEEP];
@@ -109,18 +123,40 @@ __device__ __forceinline__ void beam_step_group(const grx_beam_step_args& a, con
     // per-lane maxima below stay informative when every row holds only a few candidates: unrotated, rows
     // of c < n_keep entries would leave all but c lanes empty and nothing could be cut.
     grx_cand pre[BS_PREFETCH];
-    auto pre_col = [&](int u) { return (tid - 37 * u) & (BS_THREADS - 1); };
+    auto pre_col = [&](int u) { return (tid - 37 * u) & (NT - 1); };
     // candidate row of beam k: g_cand + k * bstride (every beam reads the group's one row when they are shared)
     const int64_t bstride = a.cand_shared ? 0 : a.cand_stride;
     const grx_cand* __restrict__ g_cand = a.cand + (a.cand_shared ? (int64_t)b : row0) * a.cand_stride;
-    if (d.reg_keys) {
+    if (HOLD == 0 && d.reg_keys) {
 #pragma unroll
         for (int u = 0; u < BS_PREFETCH; ++u) {
             // entries past a beam's count hold stale values; they are masked below
             pre[u] = cand_load<COH>(g_cand + ((u < K && pre_col(u) < cmax) ? (int64_t)u * bstride + 1 + pre_col(u) : 0));
         }
     }
-    for (int k = tid; k < K; k += BS_THREADS) {
+    // Wide groups, same idea with more threads: part q holds entry (tid - 37 k) mod BS_COLS of the beams k = q + PARTS v.
+    // Everything is asked for at once, before the counts are known (entries past a row's count are masked
+    // when the keys are built): one round trip to the candidates instead of two passes of several rounds.
+    constexpr int HN = HOLD > 0 ? HOLD : 1;
+    unsigned long long hk[HN];
+    const int hq = tid / BS_COLS;
+    auto hold_col = [&](int k) { return (tid - 37 * k) & (BS_COLS - 1); };
+    if constexpr (HOLD > 0) {
+        if (d.hold_keys) {
+#pragma unroll
+            for (int v = 0; v < HOLD; ++v) {
+                const int k = hq + PARTS * v;
+                const bool there = k < K && hold_col(k) < cmax;
+                const grx_cand e = cand_load<COH>(g_cand + (there ? (int64_t)k * bstride + 1 + hold_col(k) : 0));
+                hk[v] = ((unsigned long long)(uint32_t)e.y << 32) | (uint32_t)e.x;
+            }
+            if (tid < BS_COLS) {
+                s_pmax[tid] = 0;
+                s_prank[tid] = 0;
+            }
+        }
+    }
+    for (int k = tid; k < K; k += NT) {
         s_cnt[k] = cand_load<COH>(g_cand + (int64_t)k * bstride).x;
         s_runin[k] = a.run_score_in[row0 + k];
         s_fdone_in[k] = a.fin_done_in[row0 + k];
@@ -129,7 +165,7 @@ __device__ __forceinline__ void beam_step_group(const grx_beam_step_args& a, con
     const bool unsat_old = a.unsat[b] != 0;
     if (d.tails_in_lds) {  // K <= BS_TAIL_K rows of at most BS_TAIL_W moving positions: thread = (row, position)
         const int p = tid & (BS_TAIL_W - 1);
-        for (int k = tid / BS_TAIL_W; k < K; k += BS_THREADS / BS_TAIL_W) {
+        for (int k = tid / BS_TAIL_W; k < K; k += NT / BS_TAIL_W) {
             if (p < w_fin) s_fseq[k * BS_TAIL_W + p] = a.fin_seq_in[(row0 + k) * L + a.copy_from + p];
             if (p < w_run) s_rseq[k * BS_TAIL_W + p] = a.run_seq_in[(row0 + k) * L + a.copy_from + p];
             if (p < gpos + 1) s_fbidx[k * BS_TAIL_W + p] = a.fin_bidx_in[(row0 + k) * Lg + p];
@@ -174,8 +210,8 @@ __device__ __forceinline__ void beam_step_group(const grx_beam_step_args& a, con
     // (the n_keep-th largest of the per-thread maxima, which at least n_keep keys
     // reach) leaves a few dozen survivors; they are ranked against each other.
     bool selected = false;
-    if (d.reg_keys) {
-        // K <= BS_PREFETCH beams of at most BS_THREADS candidates, n_keep <= 64: thread t holds one entry
+    if (HOLD == 0 && d.reg_keys) {
+        // K <= BS_PREFETCH beams of at most NT candidates, n_keep <= 64: thread t holds one entry
         // of every beam.  64 partition maxima (lane-wise over the four waves) give the threshold.
         unsigned long long rk[BS_PREFETCH];
         unsigned long long tmax = 0;
@@ -190,7 +226,7 @@ __device__ __forceinline__ void beam_step_group(const grx_beam_step_args& a, con
         if (wave == 0) {
             unsigned long long pm = s_tmax[lane];
 #pragma unroll
-            for (int w = 1; w < BS_WAVES; ++w) pm = s_tmax[lane + w * GRX_WAVE] > pm ? s_tmax[lane + w * GRX_WAVE] : pm;
+            for (int w = 1; w < NW; ++w) pm = s_tmax[lane + w * GRX_WAVE] > pm ? s_tmax[lane + w * GRX_WAVE] : pm;
             int rank = 0;  // keys are unique, so the partition maxima are distinct (or 0)
             const int pm_lo = (int)(unsigned)(pm & 0xFFFFFFFFull), pm_hi = (int)(unsigned)(pm >> 32);
 #pragma unroll
@@ -215,17 +251,72 @@ __device__ __forceinline__ void beam_step_group(const grx_beam_step_args& a, con
         __syncthreads();
         const int M = s_nsurv;
         if (M <= SURV_CAP) {
-            for (int i = tid; i < M; i += BS_THREADS) {
+            for (int i = tid; i < M; i += NT) {
                 const unsigned long long kv = s_surv[i];
                 int rank = 0;
 #pragma unroll 8
                 for (int j = 0; j < M; ++j) rank += s_surv[j] > kv ? 1 : 0;
                 if (rank < n_keep) emit(rank, kv);
             }
-            for (int j = M + tid; j < n_keep; j += BS_THREADS) emit(j, 0);
+            for (int j = M + tid; j < n_keep; j += NT) emit(j, 0);
             selected = true;
         }
-    } else {
+    } else if (HOLD > 0 && d.hold_keys) {
+        if constexpr (HOLD > 0) {
+            unsigned long long tmax = 0;
+#pragma unroll
+            for (int v = 0; v < HOLD; ++v) {
+                const int k = hq + PARTS * v;
+                const bool there = k < K && hold_col(k) < cmax;
+                const unsigned long long raw = hk[v];
+                const unsigned long long kv =
+                    there ? key_at(k, hold_col(k), __int_as_float((int)(uint32_t)(raw >> 32)), (int)(uint32_t)raw) : 0ull;
+                hk[v] = kv;
+                tmax = kv > tmax ? kv : tmax;
+            }
+            // BS_COLS column maxima (over the parts) give the threshold; the ranking of a column's maximum is
+            // shared by the threads that hold the column, 1 / PARTS of the comparisons each
+            const int col = tid & (BS_COLS - 1);
+            if (tmax != 0) atomicMax(&s_pmax[col], tmax);
+            STAMP(4);
+            __syncthreads();
+            const unsigned long long pm = s_pmax[col];
+            {
+                constexpr int SPAN = BS_COLS / PARTS;
+                int cnt = 0;
+#pragma unroll 16
+                for (int j = hq * SPAN; j < (hq + 1) * SPAN; ++j) cnt += s_pmax[j] > pm ? 1 : 0;
+                if (pm != 0 && cnt != 0) atomicAdd(&s_prank[col], cnt);
+            }
+            __syncthreads();
+            if (hq == 0 && pm != 0 && s_prank[col] == n_keep - 1) s_thresh = pm;  // stays 0 with fewer than n_keep columns
+            STAMP(5);
+            __syncthreads();
+            const unsigned long long thresh = s_thresh;
+#pragma unroll
+            for (int v = 0; v < HOLD; ++v) {
+                const unsigned long long kv = hk[v];
+                if (kv != 0 && kv >= thresh) {
+                    const int at = atomicAdd(&s_nsurv, 1);
+                    if (at < SURV_CAP) s_surv[at] = kv;
+                }
+            }
+            STAMP(6);
+            __syncthreads();
+            const int M = s_nsurv;
+            if (M <= SURV_CAP) {
+                for (int i = tid; i < M; i += NT) {
+                    const unsigned long long kv = s_surv[i];
+                    int rank = 0;
+#pragma unroll 8
+                    for (int j = 0; j < M; ++j) rank += s_surv[j] > kv ? 1 : 0;
+                    if (rank < n_keep) emit(rank, kv);
+                }
+                for (int j = M + tid; j < n_keep; j += NT) emit(j, 0);
+                selected = true;
+            }
+        }
+    } else if (HOLD == 0) {
         // Wider groups: two passes over the existing candidates straight from global memory (they were
         // written a moment ago and sit in L2) -- per-thread maxima and threshold first, survivors second.
         // Two ways to deal the candidates to the threads, whichever needs fewer rounds of loads:
@@ -235,15 +326,15 @@ __device__ __forceinline__ void beam_step_group(const grx_beam_step_args& a, con
         //    of beam k (the rotation spreads short rows over all threads, which keeps the per-thread
         //    maxima informative) -- the loads of different beams need no index search and are issued
         //    back to back, which wins when the rows are long.
-        for (int k = tid; k <= K; k += BS_THREADS) {
+        for (int k = tid; k <= K; k += NT) {
             int acc = 0;
             for (int j = 0; j < k; ++j) acc += s_cnt[j] < cmax ? s_cnt[j] : cmax;
             s_base[k] = acc;
         }
         __syncthreads();
         const int total = s_base[K];
-        const int n_chunk = (cmax + BS_THREADS - 1) / BS_THREADS;
-        const bool by_column = (total + BS_THREADS - 1) / BS_THREADS > 2 * ((K + 15) / 16) * n_chunk;
+        const int n_chunk = (cmax + NT - 1) / NT;
+        const bool by_column = (total + NT - 1) / NT > 2 * ((K + 15) / 16) * n_chunk;
         auto packed_key = [&](int c) -> unsigned long long {
             int lo = 0, hi = K;
             while (hi - lo > 1) {
@@ -262,7 +353,7 @@ __device__ __forceinline__ void beam_step_group(const grx_beam_step_args& a, con
 #pragma unroll
             for (int u = 0; u < CB; ++u) {
                 const int k = k0 + u < K ? k0 + u : K - 1;
-                const int i = j * BS_THREADS + ((tid - 37 * k) & (BS_THREADS - 1));
+                const int i = j * NT + ((tid - 37 * k) & (NT - 1));
                 ok[u] = k0 + u < K && i < (s_cnt[k] < cmax ? s_cnt[k] : cmax);
                 e[u] = cand_load<COH>(g_cand + (int64_t)k * bstride + (ok[u] ? 1 + i : 0));
             }
@@ -284,7 +375,7 @@ __device__ __forceinline__ void beam_step_group(const grx_beam_step_args& a, con
             }
         } else {
 #pragma unroll 4
-            for (int c = tid; c < total; c += BS_THREADS) {
+            for (int c = tid; c < total; c += NT) {
                 const unsigned long long kv = packed_key(c);
                 tmax = kv > tmax ? kv : tmax;
             }
@@ -295,7 +386,7 @@ __device__ __forceinline__ void beam_step_group(const grx_beam_step_args& a, con
         if (tmax != 0) {
             int rank = 0;
 #pragma unroll 16
-            for (int j = 0; j < BS_THREADS; ++j) rank += s_tmax[j] > tmax ? 1 : 0;
+            for (int j = 0; j < NT; ++j) rank += s_tmax[j] > tmax ? 1 : 0;
             if (rank == n_keep - 1) s_thresh = tmax;  // stays 0 when fewer than n_keep threads hold a key
         }
         STAMP(5);
@@ -318,20 +409,20 @@ __device__ __forceinline__ void beam_step_group(const grx_beam_step_args& a, con
             }
         } else {
 #pragma unroll 4
-            for (int c = tid; c < total; c += BS_THREADS) keep(packed_key(c));
+            for (int c = tid; c < total; c += NT) keep(packed_key(c));
         }
         STAMP(6);
         __syncthreads();
         const int M = s_nsurv;
         if (M <= SURV_CAP) {
-            for (int i = tid; i < M; i += BS_THREADS) {
+            for (int i = tid; i < M; i += NT) {
                 const unsigned long long kv = s_surv[i];
                 int rank = 0;
 #pragma unroll 8
                 for (int j = 0; j < M; ++j) rank += s_surv[j] > kv ? 1 : 0;
                 if (rank < n_keep) emit(rank, kv);
             }
-            for (int j = M + tid; j < n_keep; j += BS_THREADS) emit(j, 0);
+            for (int j = M + tid; j < n_keep; j += NT) emit(j, 0);
             selected = true;
         }
     }
@@ -341,7 +432,7 @@ __device__ __forceinline__ void beam_step_group(const grx_beam_step_args& a, con
         for (int j = 0; j < n_keep; ++j) {
             unsigned long long best = 0;
             if (prev != 0) {
-                for (int c = tid; c < slots; c += BS_THREADS) {
+                for (int c = tid; c < slots; c += NT) {
                     const unsigned long long kv = key_of(c);
                     if (kv < prev && kv > best) best = kv;
                 }
@@ -350,7 +441,7 @@ __device__ __forceinline__ void beam_step_group(const grx_beam_step_args& a, con
                 __syncthreads();
                 best = s_red[j & 1][0];
 #pragma unroll
-                for (int w = 1; w < BS_WAVES; ++w) best = s_red[j & 1][w] > best ? s_red[j & 1][w] : best;
+                for (int w = 1; w < NW; ++w) best = s_red[j & 1][w] > best ? s_red[j & 1][w] : best;
             }
             if (tid == 0) emit(j, best);
             prev = best;
@@ -371,7 +462,7 @@ __device__ __forceinline__ void beam_step_group(const grx_beam_step_args& a, con
     for (int k = 0; k < K; ++k) n_done += s_fdone_in[k] != 0 ? 1 : 0;
     const bool all_done = n_done == K;
     const bool beams_full = all_done && (a.early_stopping == 1);
-    for (int j = tid; j < n_keep; j += BS_THREADS) {
+    for (int j = tid; j < n_keep; j += NT) {
         const bool hit = at_max_len || (a.eos_token_id >= 0 && s_tok[j] == a.eos_token_id);
         s_hit[j] = hit ? 1 : 0;
         const float sc = s_score[j];
@@ -408,14 +499,14 @@ __device__ __forceinline__ void beam_step_group(const grx_beam_step_args& a, con
         // of larger keys: one 64-bit compare per pair instead of three compares and their logic.
         unsigned long long* const rkey = s_surv;
         unsigned long long* const mkey = s_surv + n_keep;
-        for (int j = tid; j < n_keep + n_merged; j += BS_THREADS) {
+        for (int j = tid; j < n_keep + n_merged; j += NT) {
             const bool running = j < n_keep;
             const int i = running ? j : j - n_keep;
             s_surv[j] = ((unsigned long long)float_to_ordered(running ? s_rs[i] : s_merged[i]) << 32) |
                         (unsigned long long)(0xFFFFFFFFu - (uint32_t)i);
         }
         __syncthreads();
-        for (int idx = tid; idx < n_keep + n_merged; idx += BS_THREADS) {  // both lists at once
+        for (int idx = tid; idx < n_keep + n_merged; idx += NT) {  // both lists at once
             const bool running = idx < n_keep;
             const unsigned long long* __restrict__ keys = running ? rkey : mkey;
             const int n = running ? n_keep : n_merged;
@@ -427,14 +518,14 @@ __device__ __forceinline__ void beam_step_group(const grx_beam_step_args& a, con
             if (rank < K) (running ? s_run_idx : s_fin_idx)[rank] = j;
         }
     } else {
-        for (int j = tid; j < n_keep; j += BS_THREADS) {
+        for (int j = tid; j < n_keep; j += NT) {
             const float v = s_rs[j];
             int rank = 0;
 #pragma unroll 8
             for (int i = 0; i < n_keep; ++i) rank += ranks_before(s_rs[i], i, v, j) ? 1 : 0;
             if (rank < K) s_run_idx[rank] = j;
         }
-        for (int j = tid; j < n_merged; j += BS_THREADS) {
+        for (int j = tid; j < n_merged; j += NT) {
             const float v = s_merged[j];
             int rank = 0;
 #pragma unroll 8
@@ -451,14 +542,14 @@ __device__ __forceinline__ void beam_step_group(const grx_beam_step_args& a, con
 #endif
 
     // ---- write the per-step results
-    for (int j = tid; j < n_keep; j += BS_THREADS) {
+    for (int j = tid; j < n_keep; j += NT) {
         const int64_t o = (int64_t)b * n_keep + j;
         if (a.topk_score) a.topk_score[o] = s_score[j];
         if (a.topk_parent) a.topk_parent[o] = s_parent[j];
         if (a.topk_token) a.topk_token[o] = s_tok[j];
         if (a.topk_hit) a.topk_hit[o] = s_hit[j];
     }
-    for (int k = tid; k < K; k += BS_THREADS) {
+    for (int k = tid; k < K; k += NT) {
         const int j = s_run_idx[k];
         a.run_score_out[row0 + k] = s_rs[j];
         a.run_seq_out[(row0 + k) * L + a.cur_len] = (int64_t)s_tok[j];
@@ -486,7 +577,7 @@ __device__ __forceinline__ void beam_step_group(const grx_beam_step_args& a, con
     // and parent trails [0, gpos) (+ position gpos for carried-over finished rows)
     if (d.tails_in_lds) {
         const int p = tid & (BS_TAIL_W - 1);
-        for (int k = tid / BS_TAIL_W; k < K; k += BS_THREADS / BS_TAIL_W) {
+        for (int k = tid / BS_TAIL_W; k < K; k += NT / BS_TAIL_W) {
             const int rsrc = s_parent[s_run_idx[k]];
             const int m = s_fin_idx[k];
             if (p < w_run) a.run_seq_out[(row0 + k) * L + a.copy_from + p] = s_rseq[rsrc * BS_TAIL_W + p];
@@ -501,12 +592,12 @@ __device__ __forceinline__ void beam_step_group(const grx_beam_step_args& a, con
             }
         }
     } else {
-        for (int idx = tid; idx < K * w_run; idx += BS_THREADS) {
+        for (int idx = tid; idx < K * w_run; idx += NT) {
             const int k = idx / w_run, p = idx % w_run;
             const int src = s_parent[s_run_idx[k]];
             a.run_seq_out[(row0 + k) * L + a.copy_from + p] = a.run_seq_in[(row0 + src) * L + a.copy_from + p];
         }
-        for (int idx = tid; idx < K * w_fin; idx += BS_THREADS) {
+        for (int idx = tid; idx < K * w_fin; idx += NT) {
             const int k = idx / w_fin, p = idx % w_fin;
             const int m = s_fin_idx[k];
             const int64_t at = (row0 + k) * L + a.copy_from + p;
@@ -516,11 +607,11 @@ __device__ __forceinline__ void beam_step_group(const grx_beam_step_args& a, con
                 a.fin_seq_out[at] = a.run_seq_in[(row0 + s_parent[m - K]) * L + a.copy_from + p];
             }
         }
-        for (int idx = tid; idx < K * gpos; idx += BS_THREADS) {
+        for (int idx = tid; idx < K * gpos; idx += NT) {
             const int k = idx / gpos, q = idx % gpos;
             a.run_bidx_out[(row0 + k) * Lg + q] = a.run_bidx_in[(row0 + s_parent[s_run_idx[k]]) * Lg + q];
         }
-        for (int idx = tid; idx < K * (gpos + 1); idx += BS_THREADS) {
+        for (int idx = tid; idx < K * (gpos + 1); idx += NT) {
             const int k = idx / (gpos + 1), q = idx % (gpos + 1);
             const int m = s_fin_idx[k];
             if (m < K) {
@@ -569,7 +660,7 @@ __device__ __forceinline__ void beam_step_group(const grx_beam_step_args& a, con
             // the streaming kernel walks the rows itself; what it needs from here is the once-per-call
             // bookkeeping and the lowest row that ends in prefix_ids
             if (b == 0 && tid == 0) plan_count_bookkeeping(pc);
-            for (int k = tid; k < K; k += BS_THREADS)
+            for (int k = tid; k < K; k += NT)
                 count_row_match(pc, a.run_seq_out + (row0 + k) * L, T_next, (int)(row0 + k));
         } else {
             // Fixed-hint mode.  A new row is its parent's row plus one token, so its first valid prefix
@@ -583,10 +674,10 @@ __device__ __forceinline__ void beam_step_group(const grx_beam_step_args& a, con
             // then overwrites its own K entries.  A call on one row per group has its B plans spread over
             // entries that OTHER workgroups overwrite, so there the parents' nodes are not used and every
             // row takes the general scan (first step of a search only).
-            for (int k = tid; k < K; k += BS_THREADS)
+            for (int k = tid; k < K; k += NT)
                 s_pcode[k] = a.cand_shared ? GRX_RES_EMPTY : plan_out[row0 + k].code;
             __syncthreads();
-            for (int k = tid; k < K; k += BS_THREADS) {
+            for (int k = tid; k < K; k += NT) {
                 const int j = s_run_idx[k];
                 const int tokv = s_tok[j], pcode = s_pcode[s_parent[j]];
                 grx_row_plan pl;
@@ -614,7 +705,7 @@ __device__ __forceinline__ void beam_step_group(const grx_beam_step_args& a, con
                 if (known) plan_out[row0 + k] = pl;
             }
             __syncthreads();
-            for (int k = wave; k < K; k += BS_WAVES) {
+            for (int k = wave; k < K; k += NW) {
                 if (!s_rescan[k]) continue;
                 const grx_row_plan pl = plan_fixed_row(pc, a.run_seq_out + (row0 + k) * L, T_next, lane);
                 if (lane == 0) plan_out[row0 + k] = pl;

@@ -23,10 +23,10 @@ extern "C" __attribute__((visibility("default"))) int grx_debug_read_stamps(unsi
 
 #include "beam_body.h"
 
-template <int MAXK, int MAXKEEP, int SURV_CAP, int TAIL_K>
-__global__ __launch_bounds__(BS_THREADS) void beam_step_kernel(grx_beam_step_args a, BeamDerived d, PlanCtx pc,
-                                                               grx_row_plan* __restrict__ plan_out) {
-    beam_step_group<MAXK, MAXKEEP, SURV_CAP, TAIL_K, false>(a, d, pc, plan_out, (int)blockIdx.x);
+template <int MAXK, int MAXKEEP, int SURV_CAP, int TAIL_K, int HOLD = 0, int NT = BS_THREADS>
+__global__ __launch_bounds__(NT) void beam_step_kernel(grx_beam_step_args a, BeamDerived d, PlanCtx pc,
+                                                       grx_row_plan* __restrict__ plan_out) {
+    beam_step_group<MAXK, MAXKEEP, SURV_CAP, TAIL_K, false, HOLD, NT>(a, d, pc, plan_out, (int)blockIdx.x);
 }
 
 // Argument checks of a beam step (nothing is enqueued, no state is touched).
@@ -76,6 +76,10 @@ int grx_beam_step_derive(const char* who, const grx_beam_step_args& a, hipStream
     d.heur_div = (float)pow((double)hyp, lp);
     d.reg_keys = (a.K <= BS_PREFETCH && a.cmax <= BS_THREADS && a.n_keep <= GRX_WAVE) ? 1 : 0;
     const bool small = grx_beam_step_is_small(a);
+    d.hold_keys = (!small && a.K <= BS_MID_K && a.n_keep <= BS_MID_KEEP && a.cmax <= BS_COLS) ? 1 : 0;
+#ifdef BS_NO_HOLD  // diagnostic build: the two-pass route for every wide group
+    d.hold_keys = 0;
+#endif
     d.tails_in_lds = (a.K <= (small ? BS_SMALL_K : BS_TAIL_K) && a.cur_len + 1 - a.copy_from <= BS_TAIL_W &&
                       a.cur_len - a.prompt_len + 1 <= BS_TAIL_W) ? 1 : 0;
     *d_out = d;
@@ -93,6 +97,9 @@ void grx_beam_step_launch(const grx_beam_step_args& a, const BeamDerived& d, con
     if (grx_beam_step_is_small(a))
         hipLaunchKernelGGL((beam_step_kernel<BS_SMALL_K, BS_SMALL_KEEP, BS_SMALL_SURV, BS_SMALL_K>), dim3(a.B),
                            dim3(BS_THREADS), 0, stream, a, d, pc, plan_out);
+    else if (d.hold_keys)
+        hipLaunchKernelGGL((beam_step_kernel<BS_MID_K, BS_MID_KEEP, BS_SURV_CAP, BS_TAIL_K, BS_MID_HOLD, BS_MID_THREADS>),
+                           dim3(a.B), dim3(BS_MID_THREADS), 0, stream, a, d, pc, plan_out);
     else
         hipLaunchKernelGGL((beam_step_kernel<BS_MAXK, BS_MAXKEEP, BS_SURV_CAP, BS_TAIL_K>), dim3(a.B), dim3(BS_THREADS),
                            0, stream, a, d, pc, plan_out);
