@@ -305,12 +305,15 @@ __device__ __forceinline__ void beam_step_group(const grx_beam_step_args& a, con
             __syncthreads();
             const int M = s_nsurv;
             if (M <= SURV_CAP) {
-                for (int i = tid; i < M; i += NT) {
+                // PARTS neighbouring lanes share a survivor: each counts every PARTS-th comparison
+                for (int i = tid / PARTS; i < M; i += NT / PARTS) {
                     const unsigned long long kv = s_surv[i];
                     int rank = 0;
 #pragma unroll 8
-                    for (int j = 0; j < M; ++j) rank += s_surv[j] > kv ? 1 : 0;
-                    if (rank < n_keep) emit(rank, kv);
+                    for (int j = tid % PARTS; j < M; j += PARTS) rank += s_surv[j] > kv ? 1 : 0;
+#pragma unroll
+                    for (int o = 1; o < PARTS; o <<= 1) rank += __shfl_xor(rank, o, GRX_WAVE);
+                    if (tid % PARTS == 0 && rank < n_keep) emit(rank, kv);
                 }
                 for (int j = M + tid; j < n_keep; j += NT) emit(j, 0);
                 selected = true;
@@ -458,8 +461,12 @@ __device__ __forceinline__ void beam_step_group(const grx_beam_step_args& a, con
     // ---- stopping criteria and the two masked score vectors
     const bool at_max_len = (a.cur_len + 1) >= a.max_length;
     int n_done = 0;
+    if (K <= GRX_WAVE) {
+        n_done = (int)__popcll(__ballot(lane < K && s_fdone_in[lane < K ? lane : 0] != 0));
+    } else {
 #pragma unroll 8
-    for (int k = 0; k < K; ++k) n_done += s_fdone_in[k] != 0 ? 1 : 0;
+        for (int k = 0; k < K; ++k) n_done += s_fdone_in[k] != 0 ? 1 : 0;
+    }
     const bool all_done = n_done == K;
     const bool beams_full = all_done && (a.early_stopping == 1);
     for (int j = tid; j < n_keep; j += NT) {
@@ -478,21 +485,27 @@ __device__ __forceinline__ void beam_step_group(const grx_beam_step_args& a, con
 
     // ---- running top-K (of n_keep) and finished top-K (of K + n_keep) by rank counting
     const int n_merged = K + n_keep;
-    if (n_merged <= GRX_WAVE) {
-        // both lists fit one wave each: wave 0 ranks the running scores, wave 1 the merged finished
-        // scores, lane j against every lane's value broadcast as a scalar
-        if (wave < 2) {
-            const int n = wave == 0 ? n_keep : n_merged;
-            const float v = lane < n ? (wave == 0 ? s_rs[lane] : s_merged[lane]) : -INFINITY;
-            const int vi = __float_as_int(v);
-            int rank = 0;
-#pragma unroll
-            for (int i = 0; i < GRX_WAVE; ++i) {  // constant lane indices: scalar broadcasts, no LDS traffic
-                const float o = __int_as_float(__builtin_amdgcn_readlane(vi, i));
-                rank += (i < n && ranks_before(o, i, v, lane)) ? 1 : 0;
-            }
-            if (lane < n && rank < K) (wave == 0 ? s_run_idx : s_fin_idx)[rank] = lane;
+    if (HOLD == 0 && n_keep + n_merged <= NT) {
+        // Short lists (with many beams the 64-bit keys of the next branch cost less per comparison).  One
+        // element of either list per group of rp neighbouring lanes (rp a power of two, as many as the
+        // workgroup has to spare): each lane counts every rp-th comparison, the group adds up.
+        const int total = n_keep + n_merged;
+        int sh = 0;
+        while (sh < 4 && (total << (sh + 1)) <= NT) ++sh;
+        const int rp = 1 << sh;
+        const int idx = tid >> sh, part = tid & (rp - 1);
+        const bool running = idx < n_keep;
+        const float* __restrict__ vals = running ? s_rs : s_merged;
+        const int n = running ? n_keep : n_merged;
+        const int j = running ? idx : idx - n_keep;
+        int rank = 0;
+        if (idx < total) {
+            const float v = vals[j];
+#pragma unroll 4
+            for (int i = part; i < n; i += rp) rank += ranks_before(vals[i], i, v, j) ? 1 : 0;
         }
+        for (int o = 1; o < rp; o <<= 1) rank += __shfl_xor(rank, o, GRX_WAVE);
+        if (idx < total && part == 0 && rank < K) (running ? s_run_idx : s_fin_idx)[rank] = j;
     } else if (n_keep + n_merged <= SURV_CAP) {
         // Larger lists: (score descending, index ascending) becomes one unique 64-bit key per element --
         // kept in the survivor buffer, which is free by now -- and the rank of an element is the number
@@ -506,7 +519,8 @@ __device__ __forceinline__ void beam_step_group(const grx_beam_step_args& a, con
                         (unsigned long long)(0xFFFFFFFFu - (uint32_t)i);
         }
         __syncthreads();
-        for (int idx = tid; idx < n_keep + n_merged; idx += NT) {  // both lists at once
+        // both lists at once; PARTS neighbouring lanes share an element and count every PARTS-th comparison
+        for (int idx = tid / PARTS; idx < n_keep + n_merged; idx += NT / PARTS) {
             const bool running = idx < n_keep;
             const unsigned long long* __restrict__ keys = running ? rkey : mkey;
             const int n = running ? n_keep : n_merged;
@@ -514,8 +528,10 @@ __device__ __forceinline__ void beam_step_group(const grx_beam_step_args& a, con
             const unsigned long long mine = keys[j];
             int rank = 0;
 #pragma unroll 8
-            for (int i = 0; i < n; ++i) rank += keys[i] > mine ? 1 : 0;
-            if (rank < K) (running ? s_run_idx : s_fin_idx)[rank] = j;
+            for (int i = tid % PARTS; i < n; i += PARTS) rank += keys[i] > mine ? 1 : 0;
+#pragma unroll
+            for (int o = 1; o < PARTS; o <<= 1) rank += __shfl_xor(rank, o, GRX_WAVE);
+            if (tid % PARTS == 0 && rank < K) (running ? s_run_idx : s_fin_idx)[rank] = j;
         }
     } else {
         for (int j = tid; j < n_keep; j += NT) {
