@@ -487,6 +487,53 @@ def test_beam_step_large_random_against_oracle():
             assert torch.equal(st.beam_scores.cpu()[fin_live], ref.beam_scores[fin_live])
 
 
+@pytest.mark.parametrize("K,cmax", [(17, 256), (64, 256), (64, 257), (65, 100), (33, 1), (50, 164), (64, 64), (20, 300)])
+def test_beam_step_at_the_edges_of_the_kernel_instantiations(K, cmax):
+    """Groups of 17 .. 64 beams with rows of at most 256 candidates run the 1024-thread instantiation that holds
+    its entries in registers; one beam or one candidate more takes the two-pass route.  Both against the oracle,
+    three steps, the last with rows that end."""
+    from oracle.beam import RefBeamSearch
+
+    from genrec_amd.beam import BeamSearchState
+
+    dev = _dev()
+    g = torch.Generator().manual_seed(1000 * K + cmax)
+    B, V, eos = 3, 3000, 1
+    R = B * K
+    prompts = torch.randint(5, 90, (B, 5), generator=g).repeat_interleave(K, dim=0)
+    ref = RefBeamSearch(prompts, K, 5 + 4, eos, 0, 1.0, False)
+    st = BeamSearchState(prompts.to(dev), K, 5 + 4, eos, 0, 1.0, False, shared_prompt=True)
+    for step in range(3):
+        cnt = torch.randint(1, cmax + 1, (R,), generator=g, dtype=torch.int32)
+        cnt[1::5] = cmax  # full rows as well
+        tok = torch.zeros((R, cmax), dtype=torch.int32)
+        lp = torch.zeros((R, cmax), dtype=torch.float32)
+        dense = torch.full((R, V), float("-inf"))
+        for r in range(R):
+            n = int(cnt[r])
+            cols = torch.sort(torch.randperm(V - 2, generator=g)[:n] + 2).values
+            if step == 2 and r % 3 == 0:
+                cols = torch.tensor([eos])
+                n = 1
+                cnt[r] = 1
+            vals = -torch.rand(n, generator=g) * 20
+            tok[r, :n] = cols.int()
+            lp[r, :n] = vals
+            dense[r, cols] = vals
+        tr = ref.step(dense)
+        res = st.step(Candidates.from_parts(cnt, tok, lp, dev), V)
+        live = tr.topk_scores > LIVE
+        assert torch.equal(res.topk_scores.cpu()[live], tr.topk_scores[live]), step
+        assert torch.equal(res.topk_token.cpu().long()[live], tr.topk_token[live]), step
+        assert torch.equal(res.topk_parent.cpu().long()[live], tr.topk_parent[live]), step
+        run_live = ref.running_beam_scores > LIVE
+        assert torch.equal(st.running_sequences.cpu()[run_live], ref.running_sequences[run_live]), step
+        assert torch.equal(st.running_beam_scores.cpu()[run_live], ref.running_beam_scores[run_live]), step
+        fin_live = ref.beam_scores > LIVE
+        assert torch.equal(st.sequences.cpu()[fin_live], ref.sequences[fin_live]), step
+        assert torch.equal(st.beam_scores.cpu()[fin_live], ref.beam_scores[fin_live]), step
+
+
 def test_tie_order_is_canonical():
     """Equal scores are ordered by beam * V + token ascending (documented rule; torch.topk leaves it open)."""
     from genrec_amd.beam import BeamSearchState
