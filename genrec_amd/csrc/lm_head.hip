@@ -120,9 +120,14 @@ __global__ __launch_bounds__(LH_THREADS) void lm_head_lse_kernel(LmHeadArgs a) {
     __syncthreads();  // waits for the DMA (vmcnt) as well
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
+#ifndef LH_ABL_NODMA
         if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+#endif
         const unsigned char* wt = lds + cur * LH_BUF_BYTES;
         const unsigned char* ht = wt + LH_TILE_BYTES;
+#ifdef LH_ABL_NOMFMA
+        if (a.H < 0)
+#endif
 #pragma unroll
         for (int s = 0; s < 4; ++s) {  // K sub-steps of 16
             const int chunk = 2 * s + f_half;
