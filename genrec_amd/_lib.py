@@ -384,6 +384,29 @@ def require_cuda(t, what: str) -> None:
 
 
 def current_stream_ptr(device) -> int:
+    """Raw handle of torch's current stream on ``device`` (a torch.device or a device index)."""
     import torch
 
+    raw = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+    if raw is not None:  # no Stream object per call: this sits on every step's path
+        index = device if isinstance(device, int) else device.index
+        return int(raw(torch.cuda.current_device() if index is None else index))
     return int(torch.cuda.current_stream(device).cuda_stream)
+
+
+class _NoSwitch:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_SWITCH = _NoSwitch()
+
+
+def on_device(index: int):
+    """Context in which ``index`` is the current device; costs nothing when it already is."""
+    import torch
+
+    return _NO_SWITCH if torch.cuda.current_device() == index else torch.cuda.device(index)

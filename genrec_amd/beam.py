@@ -80,6 +80,7 @@ class BeamSearchState:
         self.fin_done = pair((B, K), torch.uint8)
         self.unsat = torch.empty(B, dtype=torch.uint8, device=dev)
         self._step_out = None
+        self._arg_blocks = [None, None]  # grx_beam_step_args per buffer half (see _step_args)
         self.reset(input_ids, planner, first_step_shared)
 
     def prompt_rows(self) -> torch.Tensor:
@@ -122,8 +123,8 @@ class BeamSearchState:
             a.plan_next = C.addressof(req)
             a.plan_one_per_group = 1 if first_step_shared else 0
         index = self.device.index if self.device.index is not None else torch.cuda.current_device()
-        with torch.cuda.device(index):
-            _lib.check(_lib.lib().grx_beam_init(C.byref(a), _lib.current_stream_ptr(self.device)))
+        with _lib.on_device(index):
+            _lib.check(_lib.lib().grx_beam_init(C.byref(a), _lib.current_stream_ptr(index)))
         del keep
         self.cur = 0  # index of the buffer that holds the current state
         self.cur_len = self.prompt_len
@@ -179,44 +180,57 @@ class BeamSearchState:
 
     def _step_args(self, cand, vocab_size: int, planner, shared_rows: bool):
         """The ``grx_beam_step_args`` of the next step (reads the current buffers, writes the others),
-        the objects that must outlive the launch, and whether the kernel plans the next processor call."""
-        a = _lib.GrxBeamStepArgs()
+        the objects that must outlive the launch, and whether the kernel plans the next processor call.
+
+        The block of each buffer half is built once and kept: the state's buffers live as long as the
+        state, the library reads the block during the call only, and a step changes a handful of fields."""
         i, o = self.cur, 1 - self.cur
-        out = self._outputs()
-        a.B, a.K, a.V, a.n_keep = self.B, self.K, int(vocab_size), self.n_keep
+        a = self._arg_blocks[i]
+        if a is None:
+            a = _lib.GrxBeamStepArgs()
+            out = self._outputs()
+            a.B, a.K, a.n_keep = self.B, self.K, self.n_keep
+            a.prompt_len, a.max_length = self.prompt_len, self.max_length
+            a.copy_from = self.copy_from
+            a.eos_token_id = -1 if self.eos is None else int(self.eos)
+            a.early_stopping = 1 if self.early_stopping is True else (2 if self.early_stopping == "never" else 0)
+            a.length_penalty = self.length_penalty
+            a.run_seq_in, a.run_seq_out = self.run_seq[i].data_ptr(), self.run_seq[o].data_ptr()
+            a.run_score_in, a.run_score_out = self.run_score[i].data_ptr(), self.run_score[o].data_ptr()
+            a.run_bidx_in, a.run_bidx_out = self.run_bidx[i].data_ptr(), self.run_bidx[o].data_ptr()
+            a.fin_seq_in, a.fin_seq_out = self.fin_seq[i].data_ptr(), self.fin_seq[o].data_ptr()
+            a.fin_score_in, a.fin_score_out = self.fin_score[i].data_ptr(), self.fin_score[o].data_ptr()
+            a.fin_bidx_in, a.fin_bidx_out = self.fin_bidx[i].data_ptr(), self.fin_bidx[o].data_ptr()
+            a.fin_done_in, a.fin_done_out = self.fin_done[i].data_ptr(), self.fin_done[o].data_ptr()
+            a.unsat = self.unsat.data_ptr()
+            a.topk_score, a.topk_parent = out.topk_scores.data_ptr(), out.topk_parent.data_ptr()
+            a.topk_token, a.topk_hit = out.topk_token.data_ptr(), out.topk_hit.data_ptr()
+            a.next_parent = out.next_parent.data_ptr()
+            self._arg_blocks[i] = a
+        a.V = int(vocab_size)
         a.cmax = cand.cmax
-        a.cur_len, a.prompt_len, a.max_length = self.cur_len, self.prompt_len, self.max_length
-        a.copy_from = self.copy_from
-        a.eos_token_id = -1 if self.eos is None else int(self.eos)
-        a.early_stopping = 1 if self.early_stopping is True else (2 if self.early_stopping == "never" else 0)
-        a.length_penalty = self.length_penalty
+        a.cur_len = self.cur_len
         assert cand.rows == (self.B if shared_rows else self.B * self.K)
         a.cand, a.cand_stride = cand.buf.data_ptr(), cand.stride
         a.cand_shared = 1 if shared_rows else 0
-        a.run_seq_in, a.run_seq_out = self.run_seq[i].data_ptr(), self.run_seq[o].data_ptr()
-        a.run_score_in, a.run_score_out = self.run_score[i].data_ptr(), self.run_score[o].data_ptr()
-        a.run_bidx_in, a.run_bidx_out = self.run_bidx[i].data_ptr(), self.run_bidx[o].data_ptr()
-        a.fin_seq_in, a.fin_seq_out = self.fin_seq[i].data_ptr(), self.fin_seq[o].data_ptr()
-        a.fin_score_in, a.fin_score_out = self.fin_score[i].data_ptr(), self.fin_score[o].data_ptr()
-        a.fin_bidx_in, a.fin_bidx_out = self.fin_bidx[i].data_ptr(), self.fin_bidx[o].data_ptr()
-        a.fin_done_in, a.fin_done_out = self.fin_done[i].data_ptr(), self.fin_done[o].data_ptr()
-        a.unsat = self.unsat.data_ptr()
-        a.topk_score, a.topk_parent = out.topk_scores.data_ptr(), out.topk_parent.data_ptr()
-        a.topk_token, a.topk_hit = out.topk_token.data_ptr(), out.topk_hit.data_ptr()
-        a.next_parent = out.next_parent.data_ptr()
         keep = None
         plan = planner is not None and self.cur_len + 1 < self.max_length
         if plan:
             req, keep = planner.plan_request(self.device, self.B * self.K)
             a.plan_next = C.addressof(req)
             keep = (req, keep)
+        else:
+            a.plan_next = None
         return a, keep, plan
 
     def _advance(self, planner, plan: bool) -> BeamStepResult:
         self.cur = 1 - self.cur
         self.cur_len += 1
         if plan:
-            planner.note_planned(self.flat_running_sequences())
+            # what flat_running_sequences() will be at the next call, without making the view
+            R = self.B * self.K
+            planner.note_planned_rows(self.run_seq[self.cur].data_ptr(), R, self.cur_len,
+                                      self.max_length if R > 1 else None)
         return self._outputs()
 
     def step(self, cand, vocab_size: int, planner=None, shared_rows: bool = False) -> BeamStepResult:
@@ -230,8 +244,8 @@ class BeamSearchState:
         processor call that made ``cand`` read 1/K of the logits."""
         a, keep, plan = self._step_args(cand, vocab_size, planner, shared_rows)
         index = self.device.index if self.device.index is not None else torch.cuda.current_device()
-        with torch.cuda.device(index):
-            _lib.check(_lib.lib().grx_beam_step(C.byref(a), _lib.current_stream_ptr(self.device)))
+        with _lib.on_device(index):
+            _lib.check(_lib.lib().grx_beam_step(C.byref(a), _lib.current_stream_ptr(index)))
         del keep
         return self._advance(planner, plan)
 

@@ -269,6 +269,7 @@ class _TrieConstrainedBase(LogitsProcessor):
         self._active: Optional[int] = None  # device index of the last call
         self._call_seq = 0                  # processor calls made so far (host side)
         self._planned: Optional[tuple] = None  # rows whose plans a beam kernel has already written
+        self._con_key, self._con_base = None, None  # the settings the cached grx_constraint was built from
 
     # -- trie ---------------------------------------------------------------------
     @property
@@ -319,7 +320,7 @@ class _TrieConstrainedBase(LogitsProcessor):
         """A ``grx_plan_request`` for the kernel that produces the rows of the next call (beam
         init / beam step), plus the objects that must outlive the launch."""
         index = device.index if device.index is not None else torch.cuda.current_device()
-        with torch.cuda.device(index):
+        with _lib.on_device(index):
             st = self._state(index)
             ws = self._workspace(index, n_rows)
         con = self._constraint()
@@ -337,6 +338,10 @@ class _TrieConstrainedBase(LogitsProcessor):
         self._planned = (rows_view.data_ptr(), rows_view.shape[0], rows_view.shape[1],
                          rows_view.stride(0) if rows_view.shape[0] > 1 else None, self._call_seq)
 
+    def note_planned_rows(self, ptr: int, n_rows: int, n_tokens: int, row_stride: Optional[int]) -> None:
+        """``note_planned`` from the numbers that describe the view (address, [R, T], row stride or None for one row)."""
+        self._planned = (ptr, n_rows, n_tokens, row_stride, self._call_seq)
+
     def _take_planned(self, rows: _lib.GrxRows, input_ids: torch.Tensor) -> None:
         token = self._planned
         self._planned = None
@@ -349,23 +354,30 @@ class _TrieConstrainedBase(LogitsProcessor):
             rows.planned = 1
 
     def _constraint(self) -> _lib.GrxConstraint:
-        con = _lib.GrxConstraint()
-        con.mode = self._mode
-        con.prefix_index = int(self.prefix_index)
-        if self.prefix_ids is None:
-            con.n_prefix = -1
-        else:
-            ids = [int(t) for t in self.prefix_ids]
-            if len(ids) > _lib.GRX_MAX_PREFIX:
-                raise _lib.GenrecHipError(f"prefix_ids longer than {_lib.GRX_MAX_PREFIX} tokens is not supported")
-            con.n_prefix = len(ids)
-            for i, t in enumerate(ids):
-                con.prefix_ids[i] = t
-        con.eos_token_id = -1 if self.eos_token_id is None else int(self.eos_token_id)
-        con.repetition_penalty = self.repetition_penalty
-        con.penalty_skip = self.prompt_ignore_length
-        con.assume_normalized = 1 if self.assume_normalized else 0
-        return con
+        """A fresh ``grx_constraint`` of the processor's current settings (callers fill in keep_top / row_bias).
+        Copied from a block that is rebuilt only when one of the settings has changed."""
+        pre = self.prefix_ids
+        key = (self._mode, self.prefix_index, None if pre is None else tuple(pre), self.eos_token_id,
+               self.repetition_penalty, self.prompt_ignore_length, self.assume_normalized)
+        if key != self._con_key:
+            con = _lib.GrxConstraint()
+            con.mode = self._mode
+            con.prefix_index = int(self.prefix_index)
+            if pre is None:
+                con.n_prefix = -1
+            else:
+                ids = [int(t) for t in pre]
+                if len(ids) > _lib.GRX_MAX_PREFIX:
+                    raise _lib.GenrecHipError(f"prefix_ids longer than {_lib.GRX_MAX_PREFIX} tokens is not supported")
+                con.n_prefix = len(ids)
+                for i, t in enumerate(ids):
+                    con.prefix_ids[i] = t
+            con.eos_token_id = -1 if self.eos_token_id is None else int(self.eos_token_id)
+            con.repetition_penalty = self.repetition_penalty
+            con.penalty_skip = self.prompt_ignore_length
+            con.assume_normalized = 1 if self.assume_normalized else 0
+            self._con_base, self._con_key = con, key
+        return _lib.GrxConstraint.from_buffer_copy(self._con_base)
 
     def _rows(self, input_ids: torch.Tensor, scores: torch.Tensor, whole_groups: bool = True
               ) -> tuple[_lib.GrxRows, torch.Tensor, torch.Tensor]:
@@ -526,7 +538,7 @@ class _TrieConstrainedBase(LogitsProcessor):
             if row_bias.dtype != torch.float32 or row_bias.numel() != rows.R or not row_bias.is_contiguous():
                 raise ValueError("row_bias must be a contiguous float32 tensor with one value per row")
         self._take_planned(rows, ids_keep)
-        with torch.cuda.device(index):
+        with _lib.on_device(index):
             st = self._state(index)
             ws = self._workspace(index, rows.R)
             con = self._constraint()
@@ -537,7 +549,7 @@ class _TrieConstrainedBase(LogitsProcessor):
                     _lib.lib().grx_constrained_beam_step(
                         self.trie.device_handle(scores_keep.device), st.ptr, C.byref(rows), C.byref(con),
                         cand.buf.data_ptr(), cand.stride, cand.cmax, ws.data_ptr(), ws.numel(), C.byref(beam_step),
-                        _lib.current_stream_ptr(scores_keep.device),
+                        _lib.current_stream_ptr(index),
                     )
                 )
             else:
