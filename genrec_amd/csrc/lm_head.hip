@@ -26,6 +26,12 @@
 // tile loop that prefetches the next tile's first step under the reduction (4.68 ms, 256 registers), and
 // four waves of 128 x 128 with one wave per SIMD and the accumulators in the AGPR half of the file, the
 // library kernel's geometry (5.48 ms: nothing hides a lone wave's LDS latency in compiler-scheduled code).
+// On top of the fragment pipelining below (4.47 -> 4.35 ms): weight tiles in a ring of three LDS slots, two steps
+// ahead (its copies alone 2.54 instead of 3.53 ms; the whole kernel 4.36 ms), tiles staged through registers
+// (global -> VGPR -> ds_write, two steps ahead: 4.42 ms), and the four-wave geometry once more, now with
+// pipelined fragments and the ring (4.70 ms).  The products alone take 3.57 ms, the copies alone 2.5 - 3.5 ms,
+// both at the same 1.8 GHz the library kernel runs at (3.71 ms): together they take 4.35 - 4.4 ms in every one of
+// these structures, so neither the copies' latency nor their path into LDS is what the library does better.
 // Counters of this kernel against the library's (rocprofv3 --pmc, same product): equal matrix-pipe busy
 // cycles, no LDS bank conflicts (library: 318 M), but 35 % of its wave cycles parked at the barrier /
 // its DMA wait against the library's 9 %.
@@ -128,25 +134,55 @@ __global__ __launch_bounds__(LH_THREADS) void lm_head_lse_kernel(LmHeadArgs a) {
 #ifdef LH_ABL_NOMFMA
         if (a.H < 0)
 #endif
+        {
+            // Four K sub-steps of 16.  Two register sets of fragments: the reads of sub-step s + 1 are issued
+            // between the products of sub-step s (one read per product, by the scheduling hints below), so
+            // the matrix pipe waits for LDS once per K step, right behind the barrier, instead of once per
+            // four products.
+            auto read_set = [&](int sub, bf16x8* fa, bf16x8* fb) {
+                const int chunk = 2 * sub + f_half;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {  // K sub-steps of 16
-            const int chunk = 2 * s + f_half;
-            bf16x8 fa[4], fb[2];
+                for (int m = 0; m < 4; ++m) {
+                    const int row = wm * 128 + m * 32 + f_row;
+                    fa[m] = *reinterpret_cast<const bf16x8*>(wt + row * 128 + lh_swz(row, chunk) * 16);
+                }
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const int row = wm * 128 + m * 32 + f_row;
-                fa[m] = *reinterpret_cast<const bf16x8*>(wt + row * 128 + lh_swz(row, chunk) * 16);
-            }
+                for (int n = 0; n < 2; ++n) {
+                    const int row = wn * 64 + n * 32 + f_row;
+                    fb[n] = *reinterpret_cast<const bf16x8*>(ht + row * 128 + lh_swz(row, chunk) * 16);
+                }
+            };
+            auto multiply = [&](const bf16x8* fa, const bf16x8* fb) {
 #pragma unroll
-            for (int n = 0; n < 2; ++n) {
-                const int row = wn * 64 + n * 32 + f_row;
-                fb[n] = *reinterpret_cast<const bf16x8*>(ht + row * 128 + lh_swz(row, chunk) * 16);
-            }
+                for (int m = 0; m < 4; ++m)
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
+                    for (int n = 0; n < 2; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[m], fb[n], acc[m][n], 0, 0, 0);
+            };
+            auto interleave = [&]() {  // 8 products, 6 fragment reads: product, read, product, read, ...
 #pragma unroll
-                for (int n = 0; n < 2; ++n)
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[m], fb[n], acc[m][n], 0, 0, 0);
+                for (int i = 0; i < 6; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            };
+            bf16x8 fa0[4], fb0[2], fa1[4], fb1[2];
+            read_set(0, fa0, fb0);
+            __builtin_amdgcn_sched_barrier(0);
+            read_set(1, fa1, fb1);
+            multiply(fa0, fb0);
+            interleave();
+            __builtin_amdgcn_sched_barrier(0);
+            read_set(2, fa0, fb0);
+            multiply(fa1, fb1);
+            interleave();
+            __builtin_amdgcn_sched_barrier(0);
+            read_set(3, fa1, fb1);
+            multiply(fa0, fb0);
+            interleave();
+            __builtin_amdgcn_sched_barrier(0);
+            multiply(fa1, fb1);
         }
         __syncthreads();  // the next tile has landed, and everybody is done with this one
     }
