@@ -192,9 +192,6 @@ class BeamSearchState:
             a.B, a.K, a.n_keep = self.B, self.K, self.n_keep
             a.prompt_len, a.max_length = self.prompt_len, self.max_length
             a.copy_from = self.copy_from
-            a.eos_token_id = -1 if self.eos is None else int(self.eos)
-            a.early_stopping = 1 if self.early_stopping is True else (2 if self.early_stopping == "never" else 0)
-            a.length_penalty = self.length_penalty
             a.run_seq_in, a.run_seq_out = self.run_seq[i].data_ptr(), self.run_seq[o].data_ptr()
             a.run_score_in, a.run_score_out = self.run_score[i].data_ptr(), self.run_score[o].data_ptr()
             a.run_bidx_in, a.run_bidx_out = self.run_bidx[i].data_ptr(), self.run_bidx[o].data_ptr()
@@ -210,6 +207,10 @@ class BeamSearchState:
         a.V = int(vocab_size)
         a.cmax = cand.cmax
         a.cur_len = self.cur_len
+        # plain attributes of the state: read every step, so that changing one between steps is honoured
+        a.eos_token_id = -1 if self.eos is None else int(self.eos)
+        a.early_stopping = 1 if self.early_stopping is True else (2 if self.early_stopping == "never" else 0)
+        a.length_penalty = self.length_penalty
         assert cand.rows == (self.B if shared_rows else self.B * self.K)
         a.cand, a.cand_stride = cand.buf.data_ptr(), cand.stride
         a.cand_shared = 1 if shared_rows else 0
