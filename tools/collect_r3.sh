@@ -1,5 +1,5 @@
 #!/bin/bash
-# Everything the round-3 profile files are made from, in one go on a fresh GPU box (run from the repo root).
+# Everything the profiles/r3_* files are made from, in one go on a fresh GPU box (run from the repo root).
 set -x
 part=${1:-all}
 if [ $part = all ] || [ $part = a ]; then
