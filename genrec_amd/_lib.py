@@ -95,6 +95,8 @@ class GrxConstraint(C.Structure):
         ("assume_normalized", C.c_int32),
         ("keep_top", C.c_int32),
         ("row_bias", C.c_void_p),
+        ("shared_prefix_len", C.c_int32),
+        ("shared_group", C.c_int32),
     ]
 
 

@@ -157,6 +157,12 @@ class BeamSearchState:
     def is_sent_finished(self) -> torch.Tensor:
         return self.fin_done[self.cur].bool()
 
+    def shared_prefix(self) -> Optional[tuple]:
+        """``(n_tokens, K)`` when the K rows of every group started from one prompt (``shared_prompt``): beam search
+        only ever re-orders whole rows inside a group, so their first ``n_tokens`` tokens stay equal.  For
+        ``candidates_into(..., shared_prefix=...)``."""
+        return (self.copy_from, self.K) if self.copy_from > 0 else None
+
     def row_bias(self) -> torch.Tensor:
         """[B*K] running beam scores: what the next step adds to a row's log-probs before ranking
         (``candidates_into(..., keep_top=state.n_keep, row_bias=state.row_bias())``)."""
@@ -257,7 +263,8 @@ class BeamSearchState:
         group's rows are done.  Same results as the two calls."""
         a, keep, plan = self._step_args(cand, scores.shape[-1], planner, False)
         processor.candidates_into(self.flat_running_sequences(), scores, cand, keep_top=keep_top,
-                                  row_bias=self.row_bias() if keep_top else None, beam_step=a)
+                                  row_bias=self.row_bias() if keep_top else None, beam_step=a,
+                                  shared_prefix=self.shared_prefix())
         del keep
         return self._advance(planner, plan)
 
@@ -331,7 +338,8 @@ def constrained_beam_search(
         else:
             flat = state.flat_running_sequences()
             logits = logits_fn(step, flat, next_parent)
-            processor.candidates_into(flat, logits, cand, keep_top=keep, row_bias=state.row_bias())
+            processor.candidates_into(flat, logits, cand, keep_top=keep, row_bias=state.row_bias(),
+                                      shared_prefix=state.shared_prefix())
             res = state.step(cand, logits.shape[-1], planner=processor)
         next_parent = res.next_parent
         step += 1

@@ -62,6 +62,8 @@ struct MlsArgs {
     // Repetition penalty (0: off) over the tokens of ids[r, pen_from:T).
     float penalty;
     int pen_from;
+    int pen_shared;        // tokens [0, pen_shared) of a row equal those of the first row of its group of pen_group rows
+    int pen_group;
     int pen_bm_bytes;      // bytes of the LDS token bitmap (one bit per token of V, rounded up to 16)
     int pen_vm_bytes;      // bytes of the LDS vector masks (one bit per 16-byte vector of a row, in words per thread)
     const int64_t* ids;
@@ -213,6 +215,9 @@ __device__ __forceinline__ void mls_body(const MlsArgs& a, const FusedBeam* fb) 
     int64_t p_tok[PEN_PER_THREAD];
     auto pen_load_ids = [&]() {
         const int64_t* __restrict__ ids_row = a.ids + (int64_t)r * a.ids_stride;
+        // the part of the row that the whole group shares is read from the group's first row: the other
+        // rows of the group that this XCD handles find it in the L2
+        const int64_t* __restrict__ ids_first = a.ids + (int64_t)(r - r % a.pen_group) * a.ids_stride;
 #pragma unroll
         for (int k = 0; k < PEN_PER_THREAD; ++k) {
             // uniform guard, clamped index: no lane waits on a branch for its token (a token loaded twice
@@ -220,7 +225,10 @@ __device__ __forceinline__ void mls_body(const MlsArgs& a, const FusedBeam* fb) 
             const int t0 = a.pen_from + k * MLS_THREADS;
             p_tok[k] = -1;
 #ifndef PEN_ABL_NOIDS
-            if (t0 < a.T) p_tok[k] = ids_row[t0 + tid < a.T ? t0 + tid : a.T - 1];
+            if (t0 < a.T) {
+                const int t = t0 + tid < a.T ? t0 + tid : a.T - 1;
+                p_tok[k] = (t < a.pen_shared ? ids_first : ids_row)[t];
+            }
 #endif
         }
     };
@@ -1067,6 +1075,10 @@ static int run_step(const char* who, const grx_trie* trie, grx_state* state, con
     if (penalise) {
         GRX_REQUIRE(con->repetition_penalty > 0.f, GRX_E_INVALID, "%s: repetition_penalty must be positive", who);
         GRX_REQUIRE(con->penalty_skip >= 0, GRX_E_INVALID, "%s: penalty_skip must be >= 0", who);
+        GRX_REQUIRE(con->shared_prefix_len >= 0 && con->shared_prefix_len <= rows->T, GRX_E_INVALID,
+                    "%s: shared_prefix_len must lie in [0, T]", who);
+        GRX_REQUIRE(con->shared_prefix_len == 0 || (con->shared_group >= 1 && rows->R % con->shared_group == 0), GRX_E_INVALID,
+                    "%s: with shared_prefix_len, R must be a multiple of shared_group >= 1", who);
         GRX_REQUIRE(rows->T - con->penalty_skip <= GRX_MAX_PENALTY_TOKENS, GRX_E_UNSUPPORTED,
                     "%s: repetition penalty over more than %d tokens per row", who, GRX_MAX_PENALTY_TOKENS);
         GRX_REQUIRE(rows->V <= PEN_MAX_V, GRX_E_UNSUPPORTED,
@@ -1099,6 +1111,9 @@ static int run_step(const char* who, const grx_trie* trie, grx_state* state, con
     if (penalise) {
         a.penalty = con->repetition_penalty;
         a.pen_from = con->penalty_skip;
+        static const bool ignore_shared = [] { const char* e = getenv("GRX_IGNORE_SHARED_PREFIX"); return e && *e == '1'; }();  // tuning
+        a.pen_shared = ignore_shared ? 0 : con->shared_prefix_len;
+        a.pen_group = a.pen_shared > 0 ? con->shared_group : 1;
         a.pen_bm_bytes = ((rows->V + 127) / 128) * 16;
         {   // a thread owns every MLS_THREADS-th vector of the row: one mask word per 32 of them
             const int nvec = rows->V / (16 / (int)dtype_size(rows->dtype));

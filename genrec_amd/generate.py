@@ -259,7 +259,8 @@ def constrained_generate(
             sliced.candidates_into(processor, ids, x, buf, one_row_per_group=one_row_per_group)
         else:
             processor.candidates_into(ids, x, buf, one_row_per_group=one_row_per_group, keep_top=keep,
-                                      row_bias=None if one_row_per_group else state.row_bias())
+                                      row_bias=None if one_row_per_group else state.row_bias(),
+                                      shared_prefix=None if one_row_per_group else state.shared_prefix())
 
     step = 0
     while True:

@@ -514,7 +514,8 @@ class _TrieConstrainedBase(LogitsProcessor):
         return min(width, keep + self.KEEP_TOP_SLACK) if keep else width
 
     def candidates_into(self, input_ids, scores, cand: "Candidates", one_row_per_group: bool = False,
-                        keep_top: int = 0, row_bias: Optional[torch.Tensor] = None, beam_step=None) -> None:
+                        keep_top: int = 0, row_bias: Optional[torch.Tensor] = None, beam_step=None,
+                        shared_prefix: Optional[tuple] = None) -> None:
         """``candidates`` writing into a caller-owned buffer (no allocation per step).
 
         ``keep_top`` > 0: rows with more than ``keep_top + KEEP_TOP_SLACK`` allowed tokens emit only their
@@ -526,6 +527,11 @@ class _TrieConstrainedBase(LogitsProcessor):
         identical copies of each (the first step of a search: the copies would give identical
         results, see ``BeamSearchState.step(..., shared_rows=True)``).  The shared counter moves
         exactly as for the full batch.
+
+        ``shared_prefix`` ``(n_tokens, group)``: the caller's promise that the first ``n_tokens`` tokens of the rows
+        are equal within every group of ``group`` consecutive rows (the prompt part of beam rows; see
+        ``BeamSearchState.shared_prefix``).  Only the fused repetition penalty uses it: it reads those tokens from
+        a group's first row, which the group's other rows then find in the cache.  Same results.
 
         ``beam_step`` (a filled ``GrxBeamStepArgs`` that reads ``cand``; see ``BeamSearchState.fused_step``):
         the beam step that consumes the candidates is carried out by this same library call
@@ -544,6 +550,8 @@ class _TrieConstrainedBase(LogitsProcessor):
             con = self._constraint()
             con.keep_top = int(keep_top)
             con.row_bias = row_bias.data_ptr() if (row_bias is not None and keep_top) else None
+            if shared_prefix is not None and self.repetition_penalty != 1.0:
+                con.shared_prefix_len, con.shared_group = min(int(shared_prefix[0]), rows.T), int(shared_prefix[1])
             if beam_step is not None:
                 _lib.check(
                     _lib.lib().grx_constrained_beam_step(

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define GRX_ABI_VERSION 14
+#define GRX_ABI_VERSION 15
 
 #if defined(GRX_BUILDING)
 #define GRX_API __attribute__((visibility("default")))
@@ -158,6 +158,15 @@ typedef struct grx_constraint {
 #define GRX_KEEP_TOP_SLACK 64
     int32_t keep_top;
     const float* row_bias;    /* device fp32 [R] or NULL; read only when keep_top > 0 */
+    /* Optional promise for the fused repetition penalty, 0 = none: the rows come in groups of
+     * shared_group consecutive rows (the beams of one prompt) whose first shared_prefix_len tokens are
+     * equal within a group -- what transformers' beam search holds for the prompt part of its rows
+     * (generation/utils.py:3316-3351 expands every prompt into num_beams equal rows and only ever
+     * re-orders whole rows inside a group).  The kernel then reads those tokens from the group's first
+     * row: one 8-byte-per-token fetch per group and XCD instead of one per row, the others are L2 hits.
+     * Results do not depend on it as long as the promise holds.  R must be a multiple of shared_group. */
+    int32_t shared_prefix_len;
+    int32_t shared_group;
 } grx_constraint;
 #define GRX_MAX_PENALTY_TOKENS 1536
 #define GRX_MAX_PENALTY_VOCAB 320000

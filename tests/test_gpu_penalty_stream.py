@@ -124,3 +124,38 @@ def test_vocabulary_too_wide_for_the_bitmap_is_refused():
         proc.candidates(ids, x)
     plain = ConstrainedLogitsProcessor(fn, 2, 3, None, 2, sync_errors=True)
     assert int(plain.candidates(ids, x).count[0]) == 1
+
+
+@pytest.mark.parametrize("rows,group,shared", [(640, 16, 180), (640, 10, 203), (48, 16, 180), (640, 1, 100)])
+def test_shared_prefix_promise_changes_nothing(rows, group, shared):
+    """``shared_prefix``: rows whose first tokens are equal within every group may have them read from the
+    group's first row.  Same candidate rows bit for bit, in rows streamed whole and in split rows, with a
+    generated suffix that differs from row to row; a row count that the group size does not divide is refused."""
+    from genrec_amd import _lib
+    from genrec_amd.logit_processor import Candidates, ConstrainedLogitsProcessor
+    from genrec_amd.trie import FlatTrie, create_prefix_allowed_tokens_fn
+
+    dev = _dev()
+    V = 8192
+    seqs, first = _trie(V, 90, seed=5)
+    fn = create_prefix_allowed_tokens_fn(FlatTrie(seqs), [11, 12, 13])
+    rng = np.random.default_rng(rows + group)
+    prompt = np.repeat(rng.integers(0, V, size=(rows // group, shared)), group, axis=0)   # equal within a group
+    own = rng.integers(0, V, size=(rows, 20))                                             # differs from row to row
+    ids = torch.from_numpy(np.concatenate([prompt, own, np.tile([11, 12, 13], (rows, 1))], axis=1).astype(np.int64)).to(dev)
+    logits = (torch.randn(rows, V, generator=torch.Generator().manual_seed(3)) * 4.0).to(torch.bfloat16).to(dev)
+
+    def run(hint):
+        proc = ConstrainedLogitsProcessor(fn, group, 3, None, 2, sync_errors=True, repetition_penalty=1.1)
+        proc.count = 0
+        cand = Candidates(rows, len(first), dev)
+        proc.candidates_into(ids, logits, cand, shared_prefix=hint)
+        return cand
+
+    plain, hinted = run(None), run((shared, group))
+    assert torch.equal(plain.buf, hinted.buf)
+    # a promise longer than the rows is cut to their length
+    assert torch.equal(plain.buf, run((shared, group)).buf)
+    if group > 1 and rows % (group + 1):
+        with pytest.raises(_lib.GenrecHipError):
+            run((shared, group + 1))

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.lib()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.grx_abi_version() == 14
+    assert lib.grx_abi_version() == 15
     assert lib.grx_candidate_stride(162) == 176 and lib.grx_candidate_stride(1) == 16
     assert lib.grx_workspace_bytes(8192) >= 0
     # argument validation happens before any device work
@@ -36,7 +36,7 @@ def test_structs_match_the_header_layout():
     from genrec_amd import _lib
 
     assert C.sizeof(_lib.GrxRows) == 56
-    assert C.sizeof(_lib.GrxConstraint) == 16 + 8 * _lib.GRX_MAX_PREFIX + 16 + 8
+    assert C.sizeof(_lib.GrxConstraint) == 16 + 8 * _lib.GRX_MAX_PREFIX + 16 + 8 + 8
     assert _lib.GrxBeamStepArgs.cand.offset == 48 and _lib.GrxBeamStepArgs.cand_stride.offset == 56
     assert C.sizeof(_lib.GrxBeamStepArgs) == 64 + 8 * 21 + 8
     assert C.sizeof(_lib.GrxBeamInitArgs) == 16 + 8 + 8 + 8 + 7 * 16 + 8 + 8 + 8

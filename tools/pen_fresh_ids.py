@@ -25,17 +25,19 @@ x = (torch.randn((R, V), device=dev) * 4).to(torch.bfloat16)
 cand = Candidates(R, trie.max_fanout, dev)
 for pen in (1.1, 1.0):
     proc = ConstrainedLogitsProcessor(fn, K, pidx, None, tok.eos_token_id, **({"repetition_penalty": pen} if pen != 1.0 else {}))
-    for mode in ("kept", "rewritten", "kept", "rewritten"):
+    for mode in ("kept", "rewritten", "kept", "rewritten", "rewritten, promise", "kept, promise", "rewritten, promise"):
         ts = []
+        # "promise": the K rows of a group share their prompt, and the call says so (shared_prefix)
+        hint = (256, K) if "promise" in mode else None
         for it in range(30):
-            if mode == "rewritten":
+            if mode.startswith("rewritten"):
                 ids.copy_(src)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             proc.count = step
             e0.record()
-            proc.candidates_into(ids, x, cand, keep_top=100)
+            proc.candidates_into(ids, x, cand, keep_top=100, shared_prefix=hint)
             e1.record()
             torch.cuda.synchronize()
             ts.append(e0.elapsed_time(e1) * 1e3)
         ts = sorted(ts[5:])
-        print(f"penalty {pen} ids {mode:10s}: median {ts[len(ts) // 2]:7.1f} us  min {ts[0]:7.1f}", flush=True)
+        print(f"penalty {pen} ids {mode:18s}: median {ts[len(ts) // 2]:7.1f} us  min {ts[0]:7.1f}", flush=True)
