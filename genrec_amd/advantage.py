@@ -63,7 +63,7 @@ def group_advantages(rewards_per_func: torch.Tensor, reward_weights: torch.Tenso
     w = reward_weights.to(device=rpf.device, dtype=torch.float32).contiguous()
     R, n_funcs = rpf.shape
     outs = [torch.empty(R, dtype=torch.float32, device=rpf.device) for _ in range(4)]
-    with torch.cuda.device(_dev_index(rpf)):
+    with _lib.on_device(_dev_index(rpf)):
         _lib.check(
             _lib.lib().grx_group_advantage(rpf.data_ptr(), w.data_ptr(), R, n_funcs, int(num_generations),
                                            _SCALE[scale_rewards], float(eps), outs[0].data_ptr(), outs[1].data_ptr(),
@@ -87,7 +87,7 @@ def group_normalize_tokenwise(values: torch.Tensor, mask: torch.Tensor, group_si
     m = mask.to(device=v.device, dtype=torch.float32).contiguous()
     R, Tc = v.shape
     out = torch.empty_like(v)
-    with torch.cuda.device(_dev_index(v)):
+    with _lib.on_device(_dev_index(v)):
         _lib.check(
             _lib.lib().grx_group_normalize_tokenwise(v.data_ptr(), m.data_ptr(), R, Tc, int(group_size), float(eps),
                                                      out.data_ptr(), _lib.current_stream_ptr(v.device))

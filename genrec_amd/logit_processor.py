@@ -453,7 +453,7 @@ class _TrieConstrainedBase(LogitsProcessor):
             if out.dtype not in (torch.float32, scores_keep.dtype):
                 raise ValueError("out must be float32 or have the dtype of scores")
         self._take_planned(rows, ids_keep)
-        with torch.cuda.device(index):
+        with _lib.on_device(index):
             st = self._state(index)
             ws = self._workspace(index, rows.R)
             con = self._constraint()
@@ -622,7 +622,7 @@ class _TrieConstrainedBase(LogitsProcessor):
         head.weight, head.weight_stride = weight.data_ptr(), weight.stride(0)
         head.H = hidden.shape[1]
         self._take_planned(rows, input_ids)
-        with torch.cuda.device(index):
+        with _lib.on_device(index):
             st = self._state(index)
             ws = self._workspace(index, rows.R)
             con = self._constraint()

@@ -36,7 +36,7 @@ def hit_ranks(beams: torch.Tensor, target: torch.Tensor) -> tuple[torch.Tensor, 
     first = torch.empty(n, dtype=torch.int32, device=dev)
     hist = torch.zeros(n_beam + 1, dtype=torch.int32, device=dev)
     index = dev.index if dev.index is not None else torch.cuda.current_device()
-    with torch.cuda.device(index):
+    with _lib.on_device(index):
         _lib.check(
             _lib.lib().grx_hit_ranks(beams.data_ptr(), target.data_ptr(), n, n_beam, L, first.data_ptr(),
                                      hist.data_ptr(), _lib.current_stream_ptr(dev))

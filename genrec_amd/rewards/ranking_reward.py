@@ -120,7 +120,7 @@ def score_code_rows(pred: torch.Tensor, pred_len: Optional[torch.Tensor], gt: to
         return cols[name].data_ptr() if name in cols else None
 
     index = dev.index if dev.index is not None else torch.cuda.current_device()
-    with torch.cuda.device(index):
+    with _lib.on_device(index):
         _lib.check(
             _lib.lib().grx_sid_rewards(
                 pred.data_ptr(), pred_len.data_ptr() if pred_len is not None else None, pred.shape[1],
@@ -152,7 +152,7 @@ def score_token_rows(pred_tok: torch.Tensor, gt_tok: torch.Tensor, code_table: t
         return t.stride(0) if t.shape[0] > 1 else max(t.shape[1], 1)
 
     index = dev.index if dev.index is not None else torch.cuda.current_device()
-    with torch.cuda.device(index):
+    with _lib.on_device(index):
         _lib.check(
             _lib.lib().grx_sid_rewards_tokens(
                 pred_tok.data_ptr(), stride(pred_tok), pred_tok.shape[1], gt_tok.data_ptr(), stride(gt_tok),
@@ -304,7 +304,7 @@ class SidRewardScorer:
             return t.stride(0) if t.shape[0] > 1 else max(t.shape[1], 1)
 
         index = self.device.index if self.device.index is not None else torch.cuda.current_device()
-        with torch.cuda.device(index):
+        with _lib.on_device(index):
             _lib.check(
                 _lib.lib().grx_rollout_score_tokens(
                     full.data_ptr(), stride(full), full.shape[1], gt.data_ptr(), stride(gt), gt.shape[1],

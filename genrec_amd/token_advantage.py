@@ -141,6 +141,6 @@ def token_prefix_advantages(
     a.scratch = scratch.data_ptr() if scratch is not None else None
     a.token_advantages = out.token_advantages.data_ptr()
     index = dev.index if dev.index is not None else torch.cuda.current_device()
-    with torch.cuda.device(index):
+    with _lib.on_device(index):
         _lib.check(_lib.lib().grx_token_prefix_advantages(C.byref(a), _lib.current_stream_ptr(dev)))
     return out
