@@ -552,6 +552,12 @@ class _TrieConstrainedBase(LogitsProcessor):
             con.row_bias = row_bias.data_ptr() if (row_bias is not None and keep_top) else None
             if shared_prefix is not None and self.repetition_penalty != 1.0:
                 con.shared_prefix_len, con.shared_group = min(int(shared_prefix[0]), rows.T), int(shared_prefix[1])
+                if self.sync_errors and con.shared_prefix_len > 0 and rows.R % max(con.shared_group, 1) == 0:
+                    # the checking mode synchronises anyway: hold the caller to its promise
+                    head = ids_keep[:, : con.shared_prefix_len].view(-1, con.shared_group, con.shared_prefix_len)
+                    if not bool((head == head[:, :1]).all()):
+                        raise ValueError("shared_prefix: the rows of a group do not share their first "
+                                         f"{con.shared_prefix_len} tokens")
             if beam_step is not None:
                 _lib.check(
                     _lib.lib().grx_constrained_beam_step(

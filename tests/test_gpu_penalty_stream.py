@@ -159,3 +159,7 @@ def test_shared_prefix_promise_changes_nothing(rows, group, shared):
     if group > 1 and rows % (group + 1):
         with pytest.raises(_lib.GenrecHipError):
             run((shared, group + 1))
+    if group > 1:  # a promise that does not hold is caught in the checking mode (sync_errors)
+        ids[1, 0] = (ids[0, 0] + 1) % V
+        with pytest.raises(ValueError):
+            run((shared, group))
