@@ -80,3 +80,27 @@ def test_rank_count_that_contradicts_the_flag_is_refused():
     assert run.returncode != 0
     assert not [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
     assert "WORLD_SIZE=1" in run.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [["--batch", "4", "--beams", "16"],
+                                   ["--batch", "8", "--beams", "50", "--trie", "Arts", "--repetition-penalty", "1.1",
+                                    "--prompt-len", "253"]])
+def test_bench_modes_at_the_launchers_shapes(shape):
+    """`bench.py` at the shapes the reference's launchers run (trl_trainer.sh:107-118: 64 rows per device;
+    evaluate.sh:31-36: 8 x 50 rows with penalty 1.1), eagerly, as a replayed HIP graph and with two library calls per
+    step: one JSON line each, the mode recorded in it, and the graph no slower than the eager loop."""
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "300", "--warmup", "30", "--no-cpu-baseline",
+            "--no-processor-surface", "--no-settle"] + shape
+    got = {}
+    for mode, flags in (("eager", []), ("graph", ["--graph"]), ("two calls", ["--no-fused-step"])):
+        run = subprocess.run(base + flags, env=env, cwd=ROOT, capture_output=True, text=True, timeout=280)
+        assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-4000:]
+        lines = [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1
+        got[mode] = json.loads(lines[0])
+        assert got[mode]["value"] > 0 and got[mode]["roofline"]["hip_graph"] == (mode == "graph")
+    assert got["graph"]["value"] >= 0.95 * got["eager"]["value"]
