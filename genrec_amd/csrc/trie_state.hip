@@ -236,7 +236,8 @@ extern "C" size_t grx_workspace_bytes(int32_t R) {
 // Number of workgroups that share one row.  Launches this small are latency-bound: what counts is
 // that all workgroups are resident at once (a second round of workgroups waits for the first to end:
 // 64 rows x 32 parts = 2048 workgroups took 37.6 us, 64 x 8 = 512 take 26.4 us) while every part still
-// streams at least two batches of loads.  Up to 256 rows: at most 512 workgroups; 257 .. 512 rows: two
+// streams at least two batches of loads.  Up to 64 rows: at most 256 workgroups (64 rows: four parts per row
+// 24.3 us per step, eight 24.8); up to 256 rows: at most 512 workgroups; 257 .. 512 rows: two
 // parts per row (400 rows: 34.8 -> 32.2 us).  Never more than 8 parts per row: the merge of a row's partial
 // pairs goes through one device-scope round trip per part, and below 64 rows it outweighs the shorter
 // streams (a whole step at 16 rows: 32 parts 27.6 us, 16 parts 23.1, 8 parts 21.4; at 32 rows: 16 parts
@@ -251,7 +252,7 @@ int grx_split_factor(int R, int row_vecs) {
         return v < 1 ? 1 : (v > 32 ? 32 : v);
     }();
     if (R <= 0 || R > GRX_SPLIT_MAX_ROWS || R > max_rows) return 1;
-    const int limit = target > 0 ? target : (R <= 256 ? 512 : 1024);
+    const int limit = target > 0 ? target : (R <= 64 ? 256 : (R <= 256 ? 512 : 1024));
     int S = 1;
     while (S * 2 <= max_parts && R * (S * 2) <= GRX_SPLIT_MAX_PARTS && R * (S * 2) <= limit && row_vecs / (S * 2) >= 512)
         S *= 2;
