@@ -74,7 +74,7 @@ struct MlsArgs {
     int keep_top;          // compact mode, > 0: rows with more candidates keep only their keep_top best
     const float* row_bias; // ... ranked by logp + row_bias[r] (null: 0), the sum the beam step ranks by
     int* split_count;      // [R] arrival counters, zero between calls
-    float2* split_part;    // [R * S] partial (max, sum)
+    float2* split_part;    // [R * S][2] partial (max, sum) and, with the penalty, (sub, add)
     // Dense output kept by the caller from call to call: last[r] is the node whose tokens row r of
     // `out` holds finite values for (written by every such call).  prefilled: `out` is -inf everywhere
     // else already, so instead of a fill pass the kernel resets just those positions.
@@ -232,7 +232,7 @@ __device__ __forceinline__ void mls_body(const MlsArgs& a, const FusedBeam* fb) 
 #endif
         }
     };
-    if constexpr (PEN && !SPLIT) pen_load_ids();
+    if constexpr (PEN && VEC) pen_load_ids();
     // The opening batches: 64 KB of the row per workgroup are in flight while the node look-up below waits
     // for its dependent scalar loads (about 10 us under load).  With one batch the memory system ran dry
     // behind every look-up -- all of them at once when a launch starts: 370.2 -> 366.5 us per launch.
@@ -326,7 +326,7 @@ __device__ __forceinline__ void mls_body(const MlsArgs& a, const FusedBeam* fb) 
     __shared__ uint32_t s_sel[PEN ? 4 : GRX_KEEP_TOP_MAX_FANOUT * 2];
     __shared__ float s_pen_red[2][MLS_WAVES];
     constexpr bool pen_on = PEN;  // a.penalty > 0: its own instantiation, so the others carry none of this
-    constexpr bool pen_stream = PEN && VEC && !SPLIT;  // marked values are caught in the stream
+    constexpr bool pen_stream = PEN && VEC;  // marked values are caught in the stream (a split row: in each part's share)
     uint32_t* const s_bm = reinterpret_cast<uint32_t*>(s_dyn);
     const unsigned char* const s_bm8 = s_dyn;
     // bit j % 32 of word [j / 32][tid] stands for vector tid + j * MLS_THREADS of the row
@@ -366,8 +366,8 @@ __device__ __forceinline__ void mls_body(const MlsArgs& a, const FusedBeam* fb) 
                 if (!(old & bit)) pen_value(E::to_float(row[tokv]), m, log_s);
             } else {
                 atomicOr(&s_bm[tokv >> 5], bit);
-                const int iv = tokv / EPV;
-                if (iv < nvec) {
+                const int iv = tokv / EPV - v_lo;  // position among the vectors this workgroup streams
+                if (iv >= 0 && iv < v_hi - v_lo) {
                     const int j = iv / MLS_THREADS;
                     atomicOr(&s_vmask[(j >> 5) * MLS_THREADS + (iv - j * MLS_THREADS)], 1u << (j & 31));
                 }
@@ -519,7 +519,7 @@ __device__ __forceinline__ void mls_body(const MlsArgs& a, const FusedBeam* fb) 
 #endif
             uint32_t word = s_vmask[w * MLS_THREADS + tid];
             while (word) {
-                const int iv = tid + (w * 32 + __ffs((int)word) - 1) * MLS_THREADS;
+                const int iv = v_lo + tid + (w * 32 + __ffs((int)word) - 1) * MLS_THREADS;
                 word &= word - 1;
                 u32x4 vec;
                 if (k < PEN_STASH) vec = s_stash[k * MLS_THREADS + tid];
@@ -535,8 +535,9 @@ __device__ __forceinline__ void mls_body(const MlsArgs& a, const FusedBeam* fb) 
             }
         }
         // marked elements behind the row's last whole vector (streamed by this same thread above)
-        for (int e = nvec * EPV + tid; e < a.V; e += MLS_THREADS)
-            if ((s_bm[e >> 5] >> (e & 31)) & 1u) own_value(E::to_float(row[e]));
+        if (!SPLIT || part == a.S - 1)
+            for (int e = nvec * EPV + tid; e < a.V; e += MLS_THREADS)
+                if ((s_bm[e >> 5] >> (e & 31)) & 1u) own_value(E::to_float(row[e]));
         tot = block_combine_pen(acc, a.penalty, pen_tot, s_m, s_s, s_pen_red);  // contains a workgroup barrier
     } else if (a.skip_stream) {  // the caller's rows are normalised: max-shifted sum 1 at maximum 0, log-sum-exp 0
         tot.m = 0.f;
@@ -551,11 +552,19 @@ __device__ __forceinline__ void mls_body(const MlsArgs& a, const FusedBeam* fb) 
         // Partials and counters only ever move through device-scope atomics (which
         // bypass the per-XCD L2), so no cache write-back or invalidate is needed.
         __shared__ int s_last;
-        unsigned long long* parts = reinterpret_cast<unsigned long long*>(a.split_part) + (int64_t)r * a.S;
+        // two words per part: (max, sum) and, with the repetition penalty, the part's two penalty sums relative
+        // to its own maximum -- sum exp(x_u - m) and sum exp(p (x_u - m)) over the marked tokens it streamed
+        unsigned long long* parts = reinterpret_cast<unsigned long long*>(a.split_part) + (int64_t)r * a.S * 2;
         if (tid == 0) {
             const unsigned long long packed =
                 ((unsigned long long)__float_as_uint(tot.s) << 32) | (unsigned long long)__float_as_uint(tot.m);
-            __hip_atomic_store(parts + part, packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(parts + part * 2, packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if constexpr (pen_stream) {
+                const float add_m = pen_tot.add * fast_exp2(-a.penalty * fmaf(tot.m, kLog2e, tot.c));
+                const unsigned long long pen_packed =
+                    ((unsigned long long)__float_as_uint(add_m) << 32) | (unsigned long long)__float_as_uint(pen_tot.sub);
+                __hip_atomic_store(parts + part * 2 + 1, pen_packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the partial has landed before the arrival is counted
             const int seen = __hip_atomic_fetch_add(&a.split_count[r], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             s_last = seen == a.S - 1;
@@ -567,21 +576,39 @@ __device__ __forceinline__ void mls_body(const MlsArgs& a, const FusedBeam* fb) 
             // lane p of every wave fetches partial p (S <= 32); merged in index order, so the
             // result does not depend on which part came last
             const int lane = tid & (GRX_WAVE - 1);
-            unsigned long long mine = 0;
-            if (lane < a.S) mine = __hip_atomic_load(parts + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned long long mine = 0, mine_pen = 0;
+            if (lane < a.S) {
+                mine = __hip_atomic_load(parts + lane * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if constexpr (pen_stream)
+                    mine_pen = __hip_atomic_load(parts + lane * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             for (int p = 0; p < a.S; ++p) {
                 const unsigned long long v = __shfl(mine, p, GRX_WAVE);
                 M = fmaxf(M, __uint_as_float((uint32_t)(v & 0xFFFFFFFFull)));
             }
             const float Mref = (M == -INFINITY) ? 0.f : M;
+            float sub = 0.f, add = 0.f;
             for (int p = 0; p < a.S; ++p) {
                 const unsigned long long v = __shfl(mine, p, GRX_WAVE);
-                sum += __uint_as_float((uint32_t)(v >> 32)) *
-                       fast_exp2((__uint_as_float((uint32_t)(v & 0xFFFFFFFFull)) - Mref) * kLog2e);
+                const float g = (__uint_as_float((uint32_t)(v & 0xFFFFFFFFull)) - Mref) * kLog2e;  // <= 0, or -inf for an empty part
+                sum += __uint_as_float((uint32_t)(v >> 32)) * fast_exp2(g);
+                if constexpr (pen_stream) {
+                    const unsigned long long w = __shfl(mine_pen, p, GRX_WAVE);
+                    const float sub_p = __uint_as_float((uint32_t)(w & 0xFFFFFFFFull)), add_p = __uint_as_float((uint32_t)(w >> 32));
+                    if (sub_p > 0.f) {
+                        sub += sub_p * fast_exp2(g);
+                        add += add_p * fast_exp2(a.penalty * g);
+                    }
+                }
+            }
+            if constexpr (pen_stream) {  // from here on relative to the row's maximum exactly
+                pen_tot.sub = sub;
+                pen_tot.add = add;
             }
         }
         tot.m = M;
         tot.s = sum;
+        tot.c = (M == -INFINITY) ? 0.f : -M * kLog2e;
         if (tid == 0)  // ready for the next call
             __hip_atomic_store(&a.split_count[r], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (OUT != OUT_COMPACT && a.prefilled) {  // the emitting workgroup tidies the kept output row
@@ -609,10 +636,12 @@ __device__ __forceinline__ void mls_body(const MlsArgs& a, const FusedBeam* fb) 
         if constexpr (pen_stream) {
             // pen_tot.add is relative to the offset the workgroup summed at: 2^(p (x_u log2e + c)) with
             // m log2e + c = residual, so exp(p (x_u - m - log s)) takes a factor 2^(-p (residual + log2 s))
+            // (a split row's merged sums are relative to the row's maximum already: no residual)
+            const float residual = SPLIT ? 0.f : fmaf(tot.m, kLog2e, tot.c);
             sub = pen_tot.sub;
-            add = pen_tot.add * fast_exp2(-a.penalty * (fmaf(tot.m, kLog2e, tot.c) + log_s * kLog2e));
+            add = pen_tot.add * fast_exp2(-a.penalty * (residual + log_s * kLog2e));
         } else {
-            if (SPLIT) pen_load_ids();
+            pen_load_ids();  // rows without 16-byte alignment: the marked tokens' logits are fetched now
             pen_mark(true, tot.m, log_s);
             sub = wave_sum(pen_sub);
             add = wave_sum(pen_add);

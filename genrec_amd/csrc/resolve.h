@@ -32,11 +32,12 @@ int grx_check_step_args(const char* who, const grx_trie* trie, const grx_state* 
 // so a row is streamed by S workgroups (S a power of two, see grx_split_factor) whose partial
 // (max, sum) pairs the last one to arrive merges through device-scope atomics.
 // The caller's workspace holds the arrival counters ([GRX_SPLIT_MAX_ROWS] int32, zero
-// between calls) followed by the partial (max, sum) pairs; the row plans come after them.
+// between calls) followed by two 8-byte words per part -- the partial (max, sum) pair and, with the
+// repetition penalty, the part's two penalty sums; the row plans come after them.
 #define GRX_SPLIT_MAX_ROWS 512
 #define GRX_SPLIT_MAX_PARTS 2048
 #define GRX_SPLIT_COUNT_BYTES (GRX_SPLIT_MAX_ROWS * 4)
-#define GRX_WS_PLAN_OFFSET (GRX_SPLIT_COUNT_BYTES + GRX_SPLIT_MAX_PARTS * 8)
+#define GRX_WS_PLAN_OFFSET (GRX_SPLIT_COUNT_BYTES + GRX_SPLIT_MAX_PARTS * 16)
 int grx_split_factor(int R, int row_vecs);
 
 // Device view of a trie handle for kernel arguments.

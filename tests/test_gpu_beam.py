@@ -332,7 +332,7 @@ def test_plans_written_by_the_beam_kernels_equal_the_planning_kernel(kind):
 
     ahead, alone = make(), make()
     g = torch.Generator().manual_seed(9)
-    plan_off = 512 * 4 + 2048 * 8  # arrival counters of split rows, their partial pairs, then the plans  # counters + partials come first in the workspace
+    plan_off = 512 * 4 + 2048 * 16  # arrival counters of split rows, their partial pairs, then the plans  # counters + partials come first in the workspace
 
     def plans(proc, R):
         ws = next(iter(proc._workspaces.values()))
@@ -688,7 +688,7 @@ def test_shared_first_step_with_hinted_prompts_in_the_fixed_hint_mode(tmp_path):
     st_full = BeamSearchState(rows, K, L, eos, pad, 1.0, False, planner=full)
     # entries B .. B*K of the plan buffer: the node of group 0's prompt, a valid parent for most tokens
     ws = next(iter(one._workspaces.values()))
-    plan_off = 512 * 4 + 2048 * 8  # arrival counters of split rows, their partial pairs, then the plans
+    plan_off = 512 * 4 + 2048 * 16  # arrival counters of split rows, their partial pairs, then the plans
     plans = ws[plan_off : plan_off + 16 * B * K].view(torch.int32).view(B * K, 4)
     torch.cuda.synchronize()
     assert int(plans[0, 0]) > 0
