@@ -109,6 +109,41 @@ def test_streamed_rows_with_penalty_match_the_float64_chain(V, dtype, kind, hist
     assert float((few.logp.cpu()[:, : len(first)].double() - want[:32]).abs().max()) <= FP32_TOL
 
 
+_SPLIT_CASES = [(rows, V, dtype, kind)
+                for V, dtype, kind in [(8192 + 4, torch.bfloat16, "tail"), (24576, torch.float32, "one_thread")]
+                for rows in (1, 7, 33, 64, 65, 130, 256, 257, 400, 512, 513)]
+_SPLIT_CASES += [(rows, 152704, torch.bfloat16, "duplicates") for rows in (1, 64, 400, 512)]  # the launchers' row counts
+
+
+@pytest.mark.parametrize("rows,V,dtype,kind", _SPLIT_CASES)
+def test_split_rows_with_penalty_at_every_part_count(rows, V, dtype, kind):
+    """Rows that several workgroups stream (8, 4 or 2 parts by row count; 513 rows: one workgroup each): every part
+    catches the penalised tokens of its own share, the part that arrives last merges the parts' sums.  The penalised
+    maximum of a row sits in a different part from row to row."""
+    from genrec_amd.logit_processor import ConstrainedLogitsProcessor
+    from genrec_amd.trie import FlatTrie, create_prefix_allowed_tokens_fn
+
+    dev = _dev()
+    seqs, first = _trie(V, 60, seed=rows)
+    fn = create_prefix_allowed_tokens_fn(FlatTrie(seqs), [11, 12, 13])
+    rng = np.random.default_rng(rows * 7 + V)
+    hist = _histories(kind, rows, 120, V, first, rng)
+    hist[:, 3] = rng.integers(0, V, size=rows)  # one penalised token anywhere in the row ...
+    ids = torch.from_numpy(np.concatenate([hist, np.tile([11, 12, 13], (rows, 1))], axis=1).astype(np.int64))
+    logits = (torch.randn(rows, V, generator=torch.Generator().manual_seed(rows)) * 4.0).to(dtype)
+    logits[torch.arange(rows), ids[:, 3]] += 25.0   # ... which is the row's maximum
+    logits = logits.to(dtype)
+    allowed = torch.from_numpy(first.astype(np.int64))
+    want = _expected(ids, logits.double(), 1.2, 0, allowed)
+    proc = ConstrainedLogitsProcessor(fn, 1, 3, None, 2, sync_errors=True, repetition_penalty=1.2)
+    for _ in range(2):  # the second call finds the arrival counters and partial sums of the first
+        proc.count = 0
+        cand = proc.candidates(ids.to(dev), logits.to(dev))
+        assert torch.equal(cand.tokens.cpu()[:, : len(first)].long(), allowed[None, :].expand(rows, -1))
+        got = cand.logp.cpu()[:, : len(first)].double()
+        assert float((got - want).abs().max()) <= FP32_TOL
+
+
 def test_vocabulary_too_wide_for_the_bitmap_is_refused():
     from genrec_amd import _lib
     from genrec_amd.logit_processor import ConstrainedLogitsProcessor
