@@ -443,15 +443,30 @@ __device__ __forceinline__ void mls_body(const MlsArgs& a, const FusedBeam* fb) 
             for (int u = 0; u < MLS_UNROLL; ++u) v[u] = vp.load(i + u * MLS_THREADS);
             consume(v, i, jb);
         }
-        for (; i < v_hi; i += MLS_THREADS) {
-            const u32x4 v = vp.load(i);
-            float f[E::kPerVec];
-            E::unpack(v, f);
-            accumulate<E::kPerVec>(acc, f);
-            if constexpr (pen_stream) {  // one of the row's last vectors (at most three per thread)
-                const int j = (i - v_lo) / MLS_THREADS;
-                vm = s_vmask[(j >> 5) * MLS_THREADS + tid];
-                if ((vm >> (j & 31)) & 1u) pen_put_aside(v);
+        // What is left of the share: at most MLS_UNROLL - 1 vectors per thread.  Asked for together (one round
+        // trip instead of one per vector, which is what a latency-bound launch of split rows feels); places
+        // beyond the share read as -inf, which adds nothing.
+        if (i < v_hi) {
+            u32x4 v[MLS_UNROLL - 1];
+#pragma unroll
+            for (int u = 0; u < MLS_UNROLL - 1; ++u) {
+                const u32x4 ninf = {E::kNegInfPacked, E::kNegInfPacked, E::kNegInfPacked, E::kNegInfPacked};
+                v[u] = ninf;
+                if (i + u * MLS_THREADS < v_hi) v[u] = vp.load(i + u * MLS_THREADS);
+            }
+            float f[(MLS_UNROLL - 1) * E::kPerVec];
+#pragma unroll
+            for (int u = 0; u < MLS_UNROLL - 1; ++u) E::unpack(v[u], f + u * E::kPerVec);
+            accumulate<(MLS_UNROLL - 1) * E::kPerVec>(acc, f);
+            if constexpr (pen_stream) {
+#pragma unroll
+                for (int u = 0; u < MLS_UNROLL - 1; ++u) {
+                    const int j = (i - v_lo) / MLS_THREADS + u;
+                    if (i + u * MLS_THREADS < v_hi) {
+                        vm = s_vmask[(j >> 5) * MLS_THREADS + tid];
+                        if ((vm >> (j & 31)) & 1u) pen_put_aside(v[u]);
+                    }
+                }
             }
         }
     }
@@ -1170,13 +1185,16 @@ static int run_step(const char* who, const grx_trie* trie, grx_state* state, con
     }
     // launches of several rounds of workgroups open every row with the deep prefetch; a launch that fits the GPU
     // in one round (few rows, split over several workgroups each) holds a few batches per thread in all: three
-    // of them up front save a round trip (64 rows 25.2 -> 24.8 us per step, 400 rows with the penalty 48.9 -> 47.5)
+    // of them up front save a round trip (64 rows 25.2 -> 24.8 us per step, 400 rows with the penalty 48.9 -> 47.5),
+    // all four when the launch has at most one workgroup per CU (64 rows 23.7 -> 23.4 us; 256 and 400 rows lose
+    // 0.6 and 1.0 us with four)
     static const int small_head = [] {
         const char* e = getenv("GRX_HEAD_BATCHES_SMALL");
-        const int v = e ? atoi(e) : 3;
-        return v < 1 ? 1 : (v > MLS_HEAD_BATCHES ? MLS_HEAD_BATCHES : v);
+        const int v = e ? atoi(e) : 0;
+        return v < 1 ? 0 : (v > MLS_HEAD_BATCHES ? MLS_HEAD_BATCHES : v);
     }();
-    a.head_batches = (int64_t)a.R * a.S >= 2048 ? MLS_HEAD_BATCHES : small_head;
+    const int64_t n_wg = (int64_t)a.R * a.S;
+    a.head_batches = n_wg >= 2048 ? MLS_HEAD_BATCHES : (small_head > 0 ? small_head : (n_wg <= 256 ? MLS_HEAD_BATCHES : 3));
     const int slot = timing_slot();
     hipEvent_t ev0 = slot >= 0 ? g_ev_start[slot] : nullptr, ev1 = slot >= 0 ? g_ev_stop[slot] : nullptr;
     if (out_kind != OUT_COMPACT && vec && !a.prefilled) {

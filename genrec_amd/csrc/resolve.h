@@ -29,7 +29,7 @@ int grx_check_step_args(const char* who, const grx_trie* trie, const grx_state* 
                         const grx_constraint* con, const void* workspace, size_t workspace_bytes, int32_t vocab = -1);
 
 // Split rows.  With few rows, one workgroup per row leaves most of the chip idle,
-// so a row is streamed by S workgroups (S a power of two, see grx_split_factor) whose partial
+// so a row is streamed by S workgroups (S <= 8, see grx_split_factor) whose partial
 // (max, sum) pairs the last one to arrive merges through device-scope atomics.
 // The caller's workspace holds the arrival counters ([GRX_SPLIT_MAX_ROWS] int32, zero
 // between calls) followed by two 8-byte words per part -- the partial (max, sum) pair and, with the

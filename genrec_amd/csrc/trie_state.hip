@@ -235,28 +235,30 @@ extern "C" size_t grx_workspace_bytes(int32_t R) {
 
 // Number of workgroups that share one row.  Launches this small are latency-bound: what counts is
 // that all workgroups are resident at once (a second round of workgroups waits for the first to end:
-// 64 rows x 32 parts = 2048 workgroups took 37.6 us, 64 x 8 = 512 take 26.4 us) while every part still
-// streams at least two batches of loads.  Up to 64 rows: at most 256 workgroups (64 rows: four parts per row
-// 24.3 us per step, eight 24.8); up to 256 rows: at most 512 workgroups; 257 .. 512 rows: two
-// parts per row (400 rows: 34.8 -> 32.2 us).  Never more than 8 parts per row: the merge of a row's partial
-// pairs goes through one device-scope round trip per part, and below 64 rows it outweighs the shorter
-// streams (a whole step at 16 rows: 32 parts 27.6 us, 16 parts 23.1, 8 parts 21.4; at 32 rows: 16 parts
-// 24.9, 8 parts 22.1).  GRX_SPLIT_ROWS / GRX_SPLIT_TARGET / GRX_SPLIT_PARTS in the environment override
-// the limits (tuning; read once).
+// 64 rows x 32 parts = 2048 workgroups took 37.6 us, 64 x 8 = 512 took 26.4 us) and that the merge of a
+// row's partial results -- a chain of device-scope round trips that grows with the parts -- does not
+// outweigh the shorter streams.  Measured under a replayed graph, whole steps, any number of parts
+// (tools/sweep_parts.sh): up to about 900 workgroups per launch (256 rows: 3 parts 31.4 us, 4 parts 32.1;
+// 400 rows: 2 parts 47.0, 3 parts 49.9; 512 rows: whole rows 41.5, 2 parts 44.0), at most four parts per
+// row (64 rows: 4 parts 23.6 us, 5 parts 23.9, 6 parts 24.2, 8 parts 24.7; 128 rows: 3 / 4 / 5 / 6 parts
+// 26.9 / 25.9 / 26.4 / 26.6) and six below 33 rows (16 rows: 4 / 5 / 6 / 8 parts 21.3 / 21.1 / 21.1 / 21.4;
+// 32 rows: 22.1 / 21.5 / 21.6 / 21.9).  GRX_SPLIT_ROWS / GRX_SPLIT_TARGET / GRX_SPLIT_PARTS in the
+// environment override the limits (tuning; read once).
 int grx_split_factor(int R, int row_vecs) {
     static const int max_rows = [] { const char* e = getenv("GRX_SPLIT_ROWS"); return e && *e ? atoi(e) : 512; }();
     static const int target = [] { const char* e = getenv("GRX_SPLIT_TARGET"); return e && *e ? atoi(e) : 0; }();
-    static const int max_parts = [] {
+    static const int env_parts = [] {
         const char* e = getenv("GRX_SPLIT_PARTS");
-        const int v = e && *e ? atoi(e) : 8;
-        return v < 1 ? 1 : (v > 32 ? 32 : v);
+        const int v = e && *e ? atoi(e) : 0;
+        return v < 0 ? 0 : (v > 32 ? 32 : v);
     }();
     if (R <= 0 || R > GRX_SPLIT_MAX_ROWS || R > max_rows) return 1;
-    const int limit = target > 0 ? target : (R <= 64 ? 256 : (R <= 256 ? 512 : 1024));
-    int S = 1;
-    while (S * 2 <= max_parts && R * (S * 2) <= GRX_SPLIT_MAX_PARTS && R * (S * 2) <= limit && row_vecs / (S * 2) >= 512)
-        S *= 2;
-    return S;
+    const int limit = target > 0 ? target : 900;
+    int S = env_parts > 0 ? env_parts : (target > 0 ? 8 : (R <= 32 ? 6 : 4));
+    if (S > GRX_SPLIT_MAX_PARTS / R) S = GRX_SPLIT_MAX_PARTS / R;
+    if (S > limit / R) S = limit / R;
+    if (S > row_vecs / 512) S = row_vecs / 512;  // every part streams at least two batches of loads
+    return S < 1 ? 1 : S;
 }
 
 TrieView grx_trie_view(const grx_trie* trie) {
