@@ -144,6 +144,34 @@ def test_split_rows_with_penalty_at_every_part_count(rows, V, dtype, kind):
         assert float((got - want).abs().max()) <= FP32_TOL
 
 
+@pytest.mark.parametrize("rows", [8, 64, 300, 640])
+def test_penalty_with_shares_that_hold_nothing_but_minus_infinity(rows):
+    """Masked logits: the first 5/8 of every row is -inf (whole parts of a split row, whole threads of a row that one
+    workgroup streams), and penalised tokens lie on both sides of the edge."""
+    from genrec_amd.logit_processor import ConstrainedLogitsProcessor
+    from genrec_amd.trie import FlatTrie, create_prefix_allowed_tokens_fn
+
+    dev = _dev()
+    V = 16384
+    seqs, first = _trie(V, 60, seed=rows + 1)
+    fn = create_prefix_allowed_tokens_fn(FlatTrie(seqs), [11, 12, 13])
+    rng = np.random.default_rng(rows)
+    hist = rng.integers(0, V, size=(rows, 200))
+    ids = torch.from_numpy(np.concatenate([hist, np.tile([11, 12, 13], (rows, 1))], axis=1).astype(np.int64))
+    logits = (torch.randn(rows, V, generator=torch.Generator().manual_seed(rows)) * 4.0).to(torch.bfloat16)
+    logits[:, : V * 5 // 8] = float("-inf")
+    allowed = torch.from_numpy(first.astype(np.int64))
+    want = _expected(ids, logits.double(), 1.3, 0, allowed)
+    proc = ConstrainedLogitsProcessor(fn, 1, 3, None, 2, sync_errors=True, repetition_penalty=1.3)
+    proc.count = 0
+    cand = proc.candidates(ids.to(dev), logits.to(dev))
+    got = cand.logp.cpu()[:, : len(first)].double()
+    assert not bool(torch.isnan(got).any())
+    live = torch.isfinite(want)
+    assert bool((torch.isfinite(got) == live).all())
+    assert float((got[live] - want[live]).abs().max()) <= FP32_TOL
+
+
 def test_vocabulary_too_wide_for_the_bitmap_is_refused():
     from genrec_amd import _lib
     from genrec_amd.logit_processor import ConstrainedLogitsProcessor
