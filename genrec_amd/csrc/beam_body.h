@@ -118,15 +118,42 @@ __device__ __forceinline__ void beam_step_group(const grx_beam_step_args& a, con
     STAMP(0);
 
     // ---- phase A: every global read the step needs is issued before the first wait.
+    // Order of issue: the per-beam scalars and the sequence tails first, the candidate entries last, and every LDS
+    // store after all of them.  (The compiler moves the first instructions of the key build up to the candidate
+    // loads and waits for them there: with the candidates asked for first, the other loads went out a round trip
+    // later, and load-and-store pairs cost one round trip each.)
+    const bool has_k = tid < K;  // K <= MAXK <= NT
+    static_assert(MAXK <= NT, "one thread per beam for the per-beam scalars");
+    int c_cnt = 0;
+    float c_run = 0.f, c_fin = 0.f;
+    unsigned char c_done = 0;
+    const int64_t bstride = a.cand_shared ? 0 : a.cand_stride;
+    // candidate row of beam k: g_cand + k * bstride (every beam reads the group's one row when they are shared)
+    const grx_cand* __restrict__ g_cand = a.cand + (a.cand_shared ? (int64_t)b : row0) * a.cand_stride;
+    if (has_k) {
+        c_cnt = cand_load<COH>(g_cand + (int64_t)tid * bstride).x;
+        c_run = a.run_score_in[row0 + tid];
+        c_done = a.fin_done_in[row0 + tid];
+        c_fin = a.fin_score_in[row0 + tid];
+    }
+    const bool unsat_old = a.unsat[b] != 0;
+    // K <= BS_TAIL_K rows of at most BS_TAIL_W moving positions: thread = (row, position)
+    const int tp = tid & (BS_TAIL_W - 1), tk0 = tid / BS_TAIL_W;
+    const bool t_on = d.tails_in_lds && tk0 < K;
+    int64_t t_fs = 0, t_rs = 0;
+    int32_t t_fb = 0, t_rb = 0;
+    if (t_on) {
+        if (tp < w_fin) t_fs = a.fin_seq_in[(row0 + tk0) * L + a.copy_from + tp];
+        if (tp < w_run) t_rs = a.run_seq_in[(row0 + tk0) * L + a.copy_from + tp];
+        if (tp < gpos + 1) t_fb = a.fin_bidx_in[(row0 + tk0) * Lg + tp];
+        if (tp < gpos) t_rb = a.run_bidx_in[(row0 + tk0) * Lg + tp];
+    }
     // Thread t prefetches one entry of each of the first BS_PREFETCH beams: entry (t - 37 u) mod 256 of
     // beam u (coalesced, rotated rows).  The rotation spreads short rows over all threads, so that the
     // per-lane maxima below stay informative when every row holds only a few candidates: unrotated, rows
     // of c < n_keep entries would leave all but c lanes empty and nothing could be cut.
     grx_cand pre[BS_PREFETCH];
     auto pre_col = [&](int u) { return (tid - 37 * u) & (NT - 1); };
-    // candidate row of beam k: g_cand + k * bstride (every beam reads the group's one row when they are shared)
-    const int64_t bstride = a.cand_shared ? 0 : a.cand_stride;
-    const grx_cand* __restrict__ g_cand = a.cand + (a.cand_shared ? (int64_t)b : row0) * a.cand_stride;
     if (HOLD == 0 && d.reg_keys) {
 #pragma unroll
         for (int u = 0; u < BS_PREFETCH; ++u) {
@@ -156,20 +183,30 @@ __device__ __forceinline__ void beam_step_group(const grx_beam_step_args& a, con
             }
         }
     }
-    for (int k = tid; k < K; k += NT) {
-        s_cnt[k] = cand_load<COH>(g_cand + (int64_t)k * bstride).x;
-        s_runin[k] = a.run_score_in[row0 + k];
-        s_fdone_in[k] = a.fin_done_in[row0 + k];
-        s_merged[k] = a.fin_score_in[row0 + k];
+    if (has_k) {
+        s_cnt[tid] = c_cnt;
+        s_runin[tid] = c_run;
+        s_fdone_in[tid] = c_done;
+        s_merged[tid] = c_fin;
     }
-    const bool unsat_old = a.unsat[b] != 0;
-    if (d.tails_in_lds) {  // K <= BS_TAIL_K rows of at most BS_TAIL_W moving positions: thread = (row, position)
-        const int p = tid & (BS_TAIL_W - 1);
-        for (int k = tid / BS_TAIL_W; k < K; k += NT / BS_TAIL_W) {
-            if (p < w_fin) s_fseq[k * BS_TAIL_W + p] = a.fin_seq_in[(row0 + k) * L + a.copy_from + p];
-            if (p < w_run) s_rseq[k * BS_TAIL_W + p] = a.run_seq_in[(row0 + k) * L + a.copy_from + p];
-            if (p < gpos + 1) s_fbidx[k * BS_TAIL_W + p] = a.fin_bidx_in[(row0 + k) * Lg + p];
-            if (p < gpos) s_rbidx[k * BS_TAIL_W + p] = a.run_bidx_in[(row0 + k) * Lg + p];
+    if (t_on) {
+        if (tp < w_fin) s_fseq[tk0 * BS_TAIL_W + tp] = t_fs;
+        if (tp < w_run) s_rseq[tk0 * BS_TAIL_W + tp] = t_rs;
+        if (tp < gpos + 1) s_fbidx[tk0 * BS_TAIL_W + tp] = t_fb;
+        if (tp < gpos) s_rbidx[tk0 * BS_TAIL_W + tp] = t_rb;
+    }
+    if (d.tails_in_lds) {  // further rows (more beams than NT / BS_TAIL_W)
+        for (int k = tk0 + NT / BS_TAIL_W; k < K; k += NT / BS_TAIL_W) {
+            int64_t fs = 0, rs = 0;
+            int32_t fb = 0, rb = 0;
+            if (tp < w_fin) fs = a.fin_seq_in[(row0 + k) * L + a.copy_from + tp];
+            if (tp < w_run) rs = a.run_seq_in[(row0 + k) * L + a.copy_from + tp];
+            if (tp < gpos + 1) fb = a.fin_bidx_in[(row0 + k) * Lg + tp];
+            if (tp < gpos) rb = a.run_bidx_in[(row0 + k) * Lg + tp];
+            if (tp < w_fin) s_fseq[k * BS_TAIL_W + tp] = fs;
+            if (tp < w_run) s_rseq[k * BS_TAIL_W + tp] = rs;
+            if (tp < gpos + 1) s_fbidx[k * BS_TAIL_W + tp] = fb;
+            if (tp < gpos) s_rbidx[k * BS_TAIL_W + tp] = rb;
         }
     }
     if (tid == 0) {
@@ -215,9 +252,20 @@ __device__ __forceinline__ void beam_step_group(const grx_beam_step_args& a, con
         // of every beam.  64 partition maxima (lane-wise over the four waves) give the threshold.
         unsigned long long rk[BS_PREFETCH];
         unsigned long long tmax = 0;
+        // counts and running scores of all beams first, unconditionally (entries beyond K are never used): read
+        // beam by beam inside the loop, every key waited for two LDS round trips of its own
+        static_assert(BS_PREFETCH <= MAXK, "one count and one running score per prefetched beam");
+        int cnt_r[BS_PREFETCH];
+        float rin_r[BS_PREFETCH];
 #pragma unroll
         for (int u = 0; u < BS_PREFETCH; ++u) {
-            rk[u] = (u < K && pre_col(u) < cmax) ? key_at(u, pre_col(u), __int_as_float(pre[u].y), pre[u].x) : 0ull;
+            cnt_r[u] = s_cnt[u];
+            rin_r[u] = s_runin[u];
+        }
+#pragma unroll
+        for (int u = 0; u < BS_PREFETCH; ++u) {
+            const bool there = u < K && pre_col(u) < cmax && pre_col(u) < cnt_r[u];
+            rk[u] = there ? make_key(__int_as_float(pre[u].y) + rin_r[u], (uint32_t)u, (uint32_t)pre[u].x) : 0ull;
             tmax = rk[u] > tmax ? rk[u] : tmax;
         }
         s_tmax[tid] = tmax;
@@ -264,13 +312,21 @@ __device__ __forceinline__ void beam_step_group(const grx_beam_step_args& a, con
     } else if (HOLD > 0 && d.hold_keys) {
         if constexpr (HOLD > 0) {
             unsigned long long tmax = 0;
+            static_assert(HOLD * PARTS <= MAXK, "one count and one running score per held beam");
+            int cnt_r[HN];
+            float rin_r[HN];
+#pragma unroll
+            for (int v = 0; v < HOLD; ++v) {  // unconditional reads (entries beyond K are never used), all in flight at once
+                cnt_r[v] = s_cnt[hq + PARTS * v];
+                rin_r[v] = s_runin[hq + PARTS * v];
+            }
 #pragma unroll
             for (int v = 0; v < HOLD; ++v) {
                 const int k = hq + PARTS * v;
-                const bool there = k < K && hold_col(k) < cmax;
+                const bool there = k < K && hold_col(k) < cmax && hold_col(k) < cnt_r[v];
                 const unsigned long long raw = hk[v];
                 const unsigned long long kv =
-                    there ? key_at(k, hold_col(k), __int_as_float((int)(uint32_t)(raw >> 32)), (int)(uint32_t)raw) : 0ull;
+                    there ? make_key(__int_as_float((int)(uint32_t)(raw >> 32)) + rin_r[v], (uint32_t)k, (uint32_t)raw) : 0ull;
                 hk[v] = kv;
                 tmax = kv > tmax ? kv : tmax;
             }
